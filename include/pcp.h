@@ -1,0 +1,127 @@
+/*
+ * pcp.h -- C ABI of libpcp.so: the registration hot path of PointcloudProcessing
+ * (ring nearest-neighbour, ring normals, point-to-point / point-to-plane
+ * least-squares tiles, hierarchical 8x8 sum, device-resident ICP loop,
+ * voxelizer / voxel stager) as hand-written gfx950 HIP kernels.
+ *
+ * The library replaces the reference's GL compute runtime,
+ * /root/reference/ComputeShader.py (class ComputeShader), behind the same
+ * call protocol; each entry point cites the method it stands in for.
+ *
+ * Conventions
+ *   - every function returns 0 on success, non-zero on failure;
+ *     pcp_last_error() returns the message of the calling thread's last failure
+ *   - pointers are HOST pointers unless the name ends in _dev
+ *   - one pcp_ctx per device and per pair in flight; calls on one ctx must be
+ *     serialised by the caller (same rule as the GL context it replaces,
+ *     ComputeShader.py:26)
+ *   - points are float32 rows of 4 (x, y, z, w); scan lines are uint32 rows of
+ *     4 (begin, end_inclusive, 1, 1) exactly as ComputeShader uploads them
+ */
+#ifndef PCP_H
+#define PCP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pcp_ctx pcp_ctx;
+
+#define PCP_MODE_POINT 0 /* LeastSquaresPoint.glsl, outlier threshold 0.1 */
+#define PCP_MODE_PLANE 1 /* LeastSquaresPlane.glsl, outlier threshold 0.2 */
+
+const char* pcp_last_error(void);
+int pcp_version(void);
+/* Number of HIP devices visible to the process (no context is created). */
+int pcp_device_count(int* count);
+
+/* ComputeShader.__init__ (:13-98) + prepareBuffers (:124-203): device buffers
+ * for clouds of at most max_points points and max_scans scan lines. */
+int pcp_create(int device, int max_points, int max_scans, pcp_ctx** out);
+/* ComputeShader.cleanup (:966-998). */
+int pcp_destroy(pcp_ctx* ctx);
+/* Run all later work of ctx on an existing hipStream_t (e.g. torch's). NULL
+ * restores the context's own stream. */
+int pcp_set_stream(pcp_ctx* ctx, void* hip_stream);
+int pcp_synchronize(pcp_ctx* ctx);
+
+/* Upload half of prepareLS / preparePointPlane / prepareNNS
+ * (ComputeShader.py:491-515, :571-585, :731-744): target cloud, scan lines
+ * (already padded or not, as the caller's method requires; n_scans is
+ * lens_data.z), origin as uploaded (4 floats, [ox,oy,oz,ox] after np.resize),
+ * ring hints reset to -1 (setInitialScanGuess :488-489).  Also precomputes the
+ * unit-sphere projection of every target point (FunctionalBase.glsl:41-48). */
+int pcp_set_target(pcp_ctx* ctx, const float* a_xyzw, int n_a,
+                   const uint32_t* scan_lines, int n_scans, const float* origin4);
+/* setInitialScanGuess (:488-489) alone. */
+int pcp_reset_hints(pcp_ctx* ctx);
+
+/* prepareDispatchNormals (:541-567), kernel NormalShader.glsl.  out_normals
+ * may be NULL (read=False); normals stay resident for pcp_ls_plane. */
+int pcp_normals(pcp_ctx* ctx, float* out_normals /* n_a x 4 */);
+
+/* dispatchNNS (:747-759), kernel NearestNeighbourScan.glsl.  hint_out may be
+ * NULL; it receives corr[:,3] (the ring each match was found on). */
+int pcp_nn(pcp_ctx* ctx, const float* b_xyzw, int n_b,
+           uint32_t* idx, float* dist2, float* hint_out);
+
+/* dispatchLS (:517-529) = LeastSquaresPoint.glsl + the ParalellHBSum tree;
+ * hb receives the summed 8x8 tile (H = hb[:6,:6], b = hb[:6,6]).
+ * debug != 0 selects identity correspondences (debug_info.x >= 1). */
+int pcp_ls_point(pcp_ctx* ctx, const float* b_xyzw, int n_b, int debug, float* hb /* 64 */);
+/* dispatchPointPlane (:587-608) = LeastSquaresPlane.glsl + tree sum.
+ * Requires pcp_normals() after the last pcp_set_target(). */
+int pcp_ls_plane(pcp_ctx* ctx, const float* b_xyzw, int n_b, float* hb /* 64 */);
+/* The per-point tiles Hs[n_b][8][8] of the same kernels (getBufferSubdata of
+ * ssbo_Hs, :399-431), materialised; for inspection and tests. */
+int pcp_ls_tiles(pcp_ctx* ctx, const float* b_xyzw, int n_b, int mode, int debug,
+                 float* tiles /* n_b x 64 */);
+
+/* prepareDispatchConcurrentHbSum (:630-727) + readSummedHB (:611-628), kernel
+ * ParalellHBSum.glsl: 64-ary tree sum of n 8x8 float tiles. */
+int pcp_hb_sum(pcp_ctx* ctx, const float* tiles /* n x 64 */, int n, float* out /* 64 */);
+/* Same on tiles already in device memory; scratch_dev must hold
+ * (ceil(n/64) + ceil(n/4096)) x 64 floats.  Runs on the context's stream,
+ * no host sync. */
+int pcp_hb_sum_dev(pcp_ctx* ctx, const float* tiles_dev, int n, float* scratch_dev,
+                   float* out_dev /* 64 */);
+
+/* Device-resident iteration loop of PointcloudIcpContainer.full_pt2pt (:71-100)
+ * and full_pt2pl (:103-144): per iteration the fused NN + tile + tree-sum
+ * kernels, the 6x6 solve (float64, rounded to float32 like np.linalg.solve on
+ * float32 input, :27,:59), rotation() (PointcloudAlignment.py:229-261) and
+ * apply_iteration_of_ls (:172-174, float64) all run on the device.
+ *   b_xyz     n_b x 3 float64 source points (as the reference keeps them)
+ *   mode      PCP_MODE_POINT: exactly max_iter iterations
+ *             PCP_MODE_PLANE: stops when mean|dx| < tol unless full_iter
+ *   dx_trace  max_iter x 6 float32, the solved steps (t, then rotation angles)
+ *   hb_trace  max_iter x 64 float32 or NULL, the summed tiles per iteration
+ *   iters     number of dispatches executed
+ *   converged 1 when the last dispatched step met tol (it is then NOT applied)
+ *   b_out     n_b x 3 float64 or NULL, the moved source points
+ * Requires pcp_set_target (and pcp_normals for the plane mode). */
+int pcp_icp_run(pcp_ctx* ctx, const double* b_xyz, int n_b, int mode, int max_iter,
+                float tol, int full_iter, float* dx_trace, float* hb_trace,
+                int* iters, int* converged, double* b_out);
+
+/* The same loop split for callers that keep data in device memory: upload
+ * once, launch without host synchronisation, fetch the small result later. */
+int pcp_upload_source(pcp_ctx* ctx, const double* b_xyz, int n_b);
+int pcp_icp_launch(pcp_ctx* ctx, int mode, int max_iter, float tol, int full_iter);
+int pcp_icp_fetch(pcp_ctx* ctx, float* dx_trace, float* hb_trace, int* iters,
+                  int* converged, double* b_out);
+/* Recompute unit vectors (+ normals when with_normals) and reset hints for the
+ * target already resident in ctx: the kernel half of prepare*, no upload. */
+int pcp_prepare_resident(pcp_ctx* ctx, int with_normals);
+
+/* Elapsed milliseconds between two points of the context's stream, measured
+ * with HIP events recorded on that stream. */
+int pcp_timer_start(pcp_ctx* ctx);
+int pcp_timer_stop(pcp_ctx* ctx, float* ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PCP_H */

@@ -1,0 +1,148 @@
+"""Generates tests/golden/*.npz.  Run from the repo root in the build container:
+
+    python -m oracle.gen_golden
+
+Needs /root/reference (read-only).  Three kinds of vectors:
+  kitti_pair.npz   data: raw xyz of sample_data velodyne frames 0000000000 / 0000000001
+  ref_kat.npz      outputs of the reference's OWN importable CPU functions
+                   (PointcloudIcpContainer, PointcloudAlignment), the known
+                   answers that pin the restatement in oracle/np_oracle.py
+  oracle_kitti.npz outputs of oracle/np_oracle.py on the KITTI pair (full-size
+                   parity targets for the HIP kernels, so GPU tests need not
+                   rerun the slow NumPy search)
+"""
+import hashlib
+import os
+import random
+import sys
+
+import numpy as np
+
+sys.dont_write_bytecode = True
+REF = "/root/reference"
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def kitti_pair():
+    d = os.path.join(REF, "sample_data/velodyne_points/data")
+    raw = [np.fromfile(os.path.join(d, f"{i:010d}.bin"), dtype=np.float32).reshape(-1, 4)[:, :3].copy()
+           for i in (0, 1)]
+    np.savez_compressed(os.path.join(OUT, "kitti_pair.npz"), raw0=raw[0], raw1=raw[1])
+    return raw
+
+
+def ref_kat(raw):
+    sys.path.insert(0, REF)
+    from LidarDataReader import LidarDataReader
+    from PointcloudAlignment import PointcloudAlignment
+    from PointcloudIcpContainer import PointcloudIcpContainer
+    icp = PointcloudIcpContainer(None, None)
+    out = {}
+    frames = []
+    for k, r in enumerate(raw):
+        p = r[np.linalg.norm(r, axis=1) > 2.5]
+        p = (LidarDataReader.aligningRotation() @ p.T).T
+        frames.append(p)
+        out[f"frame{k}_sha"] = sha(p)
+        out[f"frame{k}_n"] = len(p)
+        out[f"scan_lines{k}"] = np.array(icp.getScanLines(p, np.zeros(3)), dtype=np.int64)
+    # scan lines about a non-zero origin
+    o = np.array([0.3, -0.1, 0.25])
+    out["scan_origin"] = o
+    out["scan_lines0_o"] = np.array(icp.getScanLines(frames[0], o), dtype=np.int64)
+
+    # tests/GpuTest.py:561-582 scenario: identity correspondences on a moved 10^3 grid
+    random.seed(7)
+    g1 = icp.getUniformGrid(10)
+    R = PointcloudAlignment.randomRotation(0.4)
+    t = PointcloudAlignment.randomTranslation1() * 10
+    g2 = (R @ icp.getUniformGrid(10).T).T + t
+    g1f, g2f = g1.astype(np.float32), g2.astype(np.float32)
+    Hs, Bs = icp.getHsBsNumpy(g1f, g2f)
+    out.update(grid1=g1f, grid2=g2f, grid_H=np.sum(Hs, axis=0), grid_b=np.sum(Bs, axis=0))
+
+    # pose algebra known answers
+    rng = np.random.default_rng(3)
+    ang = rng.uniform(-0.05, 0.05, (16, 3)).astype(np.float32)
+    out["rot_angles"] = ang
+    out["rot_R"] = np.stack([PointcloudAlignment.rotation(a[0], a[1], a[2]) for a in ang])
+    pts = rng.uniform(-40, 40, (257, 3))
+    tt = rng.uniform(-0.1, 0.1, 3).astype(np.float32)
+    out.update(alg_pts=pts, alg_t=tt, alg_R=out["rot_R"][0],
+               alg_apply_ls=icp.apply_iteration_of_ls(pts, tt, out["rot_R"][0]),
+               alg_apply_step=icp.applyIcpStep(pts, out["rot_R"][0], tt))
+    Ropt, topt = icp.uniform_optimal_icp(icp.applyIcpStep(icp.getUniformGrid(10), out["rot_R"][1], tt),
+                                         icp.getUniformGrid(10))
+    out.update(alg_Ropt=Ropt, alg_topt=topt, uniform_grid=icp.getUniformGrid(10))
+    # np.linalg.solve on float32 input, as dispatchPointToPoint does (:27)
+    A = rng.normal(size=(8, 6, 6)).astype(np.float32)
+    A = np.einsum("nij,nkj->nik", A, A) + np.eye(6, dtype=np.float32)
+    bb = rng.normal(size=(8, 6)).astype(np.float32)
+    out.update(solve_H=A, solve_b=bb, solve_dx=np.stack([np.linalg.solve(A[i], -bb[i]) for i in range(8)]))
+
+    # tests/FunctionalTesting.py:250-277 scenario: LS ICP with known correspondences
+    random.seed(11)
+    shape = icp.getUniformShape()
+    R = PointcloudAlignment.randomRotation(0.01)
+    t = PointcloudAlignment.randomTranslation1() * 0.01
+    moved = (R @ shape.T).T + t
+    cur = moved.copy()
+    for _ in range(5):
+        tl, rl = icp.icp_step_LS_vector(shape, cur)
+        cur = icp.apply_iteration_of_ls(cur, tl, PointcloudAlignment.rotation(rl[0], rl[1], rl[2]))
+    out.update(shape=shape, shape_moved=moved, shape_after5=cur)
+
+    # legacy exact NN (PointcloudIcpContainer.py:467-472) on a subsample
+    tree = icp.getKDTree(frames[0])
+    sub = frames[1][::97]
+    _, _, dist = icp.getNearestNeighbours(tree, frames[0], sub)
+    dd, ii = tree.query(sub)
+    out.update(kd_query_stride=97, kd_idx=ii.astype(np.int64), kd_dist=dd)
+    np.savez_compressed(os.path.join(OUT, "ref_kat.npz"), **out)
+    return frames
+
+
+def oracle_kitti(frames):
+    from oracle import np_oracle as O
+    A, B = frames
+    o = np.zeros(3)
+    out = {}
+    sl = O.get_scan_lines(A, o)
+    a4, b4, o4 = O.pad_points(A), O.pad_points(B), O.origin4(o)
+    scan = O.pad_scan_lines(sl).astype(np.int64)
+    hint = np.full(len(b4), -1, np.float32)
+    idx, d2, h1 = O.nearest_neighbour_scan(a4, b4, o4, scan, 100, hint)
+    idx2, d22, h2 = O.nearest_neighbour_scan(a4, b4, o4, scan, 100, h1)
+    out.update(nn_idx=idx, nn_dist=d2, nn_hint=h1.astype(np.int8), nn2_idx_sha=sha(idx2), nn2_dist_sha=sha(d22))
+    nrm = O.normals(a4, o4, scan, 100)
+    out.update(normals_sha=sha(nrm), normals_sub=nrm[::16].copy())
+    # non-zero origin: the [ox,oy,oz,ox] quirk is live
+    o2 = np.array([0.3, -0.1, 0.25])
+    sl2 = O.get_scan_lines(A, o2)
+    scan2 = O.pad_scan_lines(sl2).astype(np.int64)
+    idx_o, d_o, _ = O.nearest_neighbour_scan(a4, b4[::8], O.origin4(o2), scan2, 100,
+                                             np.full(len(b4[::8]), -1, np.float32))
+    out.update(nn_o_idx=idx_o, nn_o_dist=d_o)
+    tr = []
+    t_opt, R_opt = O.full_pt2pt(A, B, o, iterations=20, trace=tr)
+    out.update(p2p_t=t_opt, p2p_R=R_opt, p2p_hb=np.stack([np.column_stack([h, b]) for h, b, _ in tr]),
+               p2p_dx=np.stack([d for _, _, d in tr]))
+    tr = []
+    t_opt, R_opt = O.full_pt2pl(A, B, o, iterations=10, trace=tr)
+    out.update(p2l_t=t_opt, p2l_R=R_opt, p2l_hb=np.stack([np.column_stack([h, b]) for h, b, _ in tr]),
+               p2l_dx=np.stack([d for _, _, d in tr]))
+    np.savez_compressed(os.path.join(OUT, "oracle_kitti.npz"), **out)
+
+
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    raw = kitti_pair()
+    frames = ref_kat(raw)
+    if "--no-oracle" not in sys.argv:
+        oracle_kitti(frames)
+    for f in sorted(os.listdir(OUT)):
+        print(f, os.path.getsize(os.path.join(OUT, f)))

@@ -1,0 +1,10 @@
+"""MI355X-native registration hot path of PointcloudProcessing.
+
+The classes keep the reference's names and call surface; the compute backend
+is libpcp.so (hand-written gfx950 HIP kernels behind the C ABI of
+include/pcp.h).
+"""
+from ._lib import LIB_PATH, PcpError, load  # noqa: F401
+from .alignment import PointcloudAlignment  # noqa: F401
+from .compute_shader import MODE_PLANE, MODE_POINT, ComputeShader  # noqa: F401
+from .icp_container import PointcloudIcpContainer  # noqa: F401

@@ -1,0 +1,93 @@
+"""ctypes binding of libpcp.so (C ABI declared in include/pcp.h).
+
+The library is the only compute backend: when it is missing or a call fails,
+an exception is raised -- there is no CPU fallback.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpcp.so")
+
+_lib = None
+
+
+class PcpError(RuntimeError):
+    pass
+
+
+def _ptr(arr, ctype):
+    return arr.ctypes.data_as(C.POINTER(ctype))
+
+
+# name -> (restype, argtypes); every symbol include/pcp.h declares
+_f32p, _f64p, _u32p, _i32p = (C.POINTER(C.c_float), C.POINTER(C.c_double),
+                              C.POINTER(C.c_uint32), C.POINTER(C.c_int))
+_ctx = C.c_void_p
+SIGNATURES = {
+    "pcp_last_error": (C.c_char_p, []),
+    "pcp_version": (C.c_int, []),
+    "pcp_device_count": (C.c_int, [_i32p]),
+    "pcp_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(_ctx)]),
+    "pcp_destroy": (C.c_int, [_ctx]),
+    "pcp_set_stream": (C.c_int, [_ctx, C.c_void_p]),
+    "pcp_synchronize": (C.c_int, [_ctx]),
+    "pcp_set_target": (C.c_int, [_ctx, _f32p, C.c_int, _u32p, C.c_int, _f32p]),
+    "pcp_reset_hints": (C.c_int, [_ctx]),
+    "pcp_normals": (C.c_int, [_ctx, _f32p]),
+    "pcp_nn": (C.c_int, [_ctx, _f32p, C.c_int, _u32p, _f32p, _f32p]),
+    "pcp_ls_point": (C.c_int, [_ctx, _f32p, C.c_int, C.c_int, _f32p]),
+    "pcp_ls_plane": (C.c_int, [_ctx, _f32p, C.c_int, _f32p]),
+    "pcp_ls_tiles": (C.c_int, [_ctx, _f32p, C.c_int, C.c_int, C.c_int, _f32p]),
+    "pcp_hb_sum": (C.c_int, [_ctx, _f32p, C.c_int, _f32p]),
+    "pcp_hb_sum_dev": (C.c_int, [_ctx, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "pcp_icp_run": (C.c_int, [_ctx, _f64p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int,
+                              _f32p, _f32p, _i32p, _i32p, _f64p]),
+    "pcp_upload_source": (C.c_int, [_ctx, _f64p, C.c_int]),
+    "pcp_icp_launch": (C.c_int, [_ctx, C.c_int, C.c_int, C.c_float, C.c_int]),
+    "pcp_icp_fetch": (C.c_int, [_ctx, _f32p, _f32p, _i32p, _i32p, _f64p]),
+    "pcp_prepare_resident": (C.c_int, [_ctx, C.c_int]),
+    "pcp_timer_start": (C.c_int, [_ctx]),
+    "pcp_timer_stop": (C.c_int, [_ctx, _f32p]),
+}
+
+
+def load():
+    """Loads libpcp.so once; raises PcpError when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise PcpError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError here = header and library disagree
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != 0:
+        raise PcpError(load().pcp_last_error().decode("utf-8", "replace"))
+
+
+def f32p(a):
+    return None if a is None else _ptr(a, C.c_float)
+
+
+def f64p(a):
+    return None if a is None else _ptr(a, C.c_double)
+
+
+def u32p(a):
+    return None if a is None else _ptr(a, C.c_uint32)
+
+
+def as_f32c(a):
+    return np.ascontiguousarray(a, dtype=np.float32)

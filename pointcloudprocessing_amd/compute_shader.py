@@ -1,0 +1,210 @@
+"""Drop-in for the reference's GL compute runtime (ComputeShader.py, class
+ComputeShader) over libpcp.so's HIP kernels.
+
+Same method names, argument orders, return shapes and staging-array
+attributes as the reference; file:line citations point at
+/root/reference/ComputeShader.py.  No GL context, no shader compilation:
+the kernels are precompiled gfx950 code objects inside libpcp.so.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import PcpError, check, f32p, f64p, u32p
+
+MODE_POINT = 0
+MODE_PLANE = 1
+
+
+class ComputeShader:
+    """ComputeShader.py:11-98.  One instance owns one device context."""
+
+    def __init__(self, maxPointsPerCloud=200000, maxScans=100, device=0):
+        self._lib = _lib.load()
+        self.bigint = 9999999
+        self.float_size = 4
+        self.max_points_per_voxel = 4096
+        self.maxPointsPerCloud = maxPointsPerCloud
+        self.maxScans = maxScans
+        self.device = device
+        self.main_shadercode_regex = "void main(){}"
+
+        self.origin = None
+        self.debug_info = None
+        self.lens_data = None
+        self.hs_out = None
+        self.corr_out = None
+        self.normals_out_a = None
+        self.prev_out_a = 0
+        self.prev_out_b = 0
+        self.voxel_stage_out = None
+
+        self._ctx = C.c_void_p()
+        check(self._lib.pcp_create(int(device), int(maxPointsPerCloud), int(maxScans), C.byref(self._ctx)))
+        self._active = None          # which prepare* ran last
+        self.reallocate_out(np.array([maxPointsPerCloud, maxPointsPerCloud, 0, 0]))
+
+    # ------------------------------------------------------------------ helpers
+    def reallocate_out(self, lens_data):
+        """:231-241 -- backend-owned staging arrays, reused by the next call."""
+        len_a, len_b = int(lens_data[0]), int(lens_data[1])
+        if len_b != self.prev_out_b:
+            self.corr_out = np.zeros((len_b, 4), dtype=np.float32)
+            self.prev_out_b = len_b
+        if len_a != self.prev_out_a:
+            self.normals_out_a = np.zeros((len_a, 4), dtype=np.float32)
+            self.prev_out_a = len_a
+
+    def pad_points(self, points):
+        """:956-961"""
+        points = np.asarray(points)
+        if points.shape[1] == 4:
+            return np.ascontiguousarray(points.astype(np.float32))
+        padded = np.zeros((points.shape[0], 4), dtype=np.float32)
+        padded[:, :3] = points.astype(np.float32)
+        return padded
+
+    def padScanlines(self, scan_lines):
+        """:531-539 -- pad rows are (1, 1, 1, 1)."""
+        scan_lines = np.array(scan_lines).astype(np.uint32)
+        if scan_lines.shape != (self.maxScans, 4):
+            if scan_lines.shape[0] > self.maxScans:
+                # the reference overflows its SSBO here and re-raises the GL error (:549-555)
+                raise PcpError(f"{scan_lines.shape[0]} scan lines do not fit maxScans = {self.maxScans}")
+            padded = np.ones((self.maxScans, 4), dtype=np.uint32)
+            padded[:scan_lines.shape[0], :scan_lines.shape[1]] = scan_lines
+            return padded
+        return scan_lines
+
+    def saveUniformInfo(self, points_a, points_b, origin, scan_lines, debug_mode):
+        """:435-445 -- origin becomes [ox, oy, oz, ox] (np.resize repeats)."""
+        self.origin = np.resize(origin, (4,)).astype(np.float32)
+        self.debug_info = np.array([0, 0, 0, 0]).astype(np.float32)
+        if debug_mode:
+            self.debug_info[0] = 1.123
+        self.lens_data = np.array([len(points_a), len(points_b), len(scan_lines), 0]).astype(np.uint32)
+
+    def _set_target(self, points_a, scan_lines4, origin):
+        a4 = self.pad_points(points_a)
+        lines = np.ascontiguousarray(scan_lines4, dtype=np.uint32)
+        o4 = np.resize(origin, (4,)).astype(np.float32)
+        check(self._lib.pcp_set_target(self._ctx, f32p(a4), len(a4), u32p(lines), len(lines), f32p(o4)))
+
+    # ------------------------------------------------------------------ point to point
+    def prepareLS(self, points_a, scan_lines, points_b, origin, debug_mode=False):
+        """:491-515 -- scan lines are NOT padded to maxScans on this path."""
+        scan_lines = np.array(scan_lines).astype(np.uint32)
+        padded = np.ones((scan_lines.shape[0], 4), dtype=np.uint32)
+        padded[:, :2] = scan_lines
+        self._set_target(points_a, padded, origin)
+        self.saveUniformInfo(points_a, points_b, origin, padded, debug_mode)
+        self._active = "ls"
+
+    def dispatchLS(self, points_b):
+        """:517-529 -> (H (6,6) float32, b (6,) float32)."""
+        b4 = self.pad_points(points_b)
+        hb = np.zeros((8, 8), dtype=np.float32)
+        debug = int(self.debug_info is not None and self.debug_info[0] >= 1.0)
+        check(self._lib.pcp_ls_point(self._ctx, f32p(b4), len(b4), debug, f32p(hb)))
+        return hb[:6, :6], hb[:, 6][:6]
+
+    # ------------------------------------------------------------------ normals / point to plane
+    def prepareDispatchNormals(self, points_a, scan_lines, origin, read=True):
+        """:541-567 -- result in self.normals_out_a (N_a, 4)."""
+        scan_lines = self.padScanlines(scan_lines)
+        self._set_target(points_a, scan_lines, origin)
+        self.lens_data = np.array([len(points_a), len(points_a), len(scan_lines), 0])
+        if read:
+            self.reallocate_out(self.lens_data)
+            check(self._lib.pcp_normals(self._ctx, f32p(self.normals_out_a)))
+        else:
+            check(self._lib.pcp_normals(self._ctx, None))
+
+    def preparePointPlane(self, points_a, scan_lines, points_b, origin, debug_mode=False):
+        """:571-585"""
+        self.prepareDispatchNormals(points_a, scan_lines, origin, read=False)
+        scan_lines = self.padScanlines(scan_lines)
+        self.saveUniformInfo(points_a, points_b, origin, scan_lines, debug_mode)
+        self._active = "plane"
+
+    def dispatchPointPlane(self, points_b):
+        """:587-608 -> (H, b)."""
+        b4 = self.pad_points(points_b)
+        hb = np.zeros((8, 8), dtype=np.float32)
+        check(self._lib.pcp_ls_plane(self._ctx, f32p(b4), len(b4), f32p(hb)))
+        return hb[:6, :6], hb[:, 6][:6]
+
+    # ------------------------------------------------------------------ stand-alone NN
+    def prepareNNS(self, points_a, scan_lines, points_b, origin):
+        """:731-744"""
+        scan_lines = self.padScanlines(scan_lines)
+        self._set_target(points_a, scan_lines, origin)
+        self.saveUniformInfo(points_a, points_b, origin, scan_lines, False)
+        self._active = "nns"
+
+    def dispatchNNS(self, points_b):
+        """:747-759 -> (idx uint32[N_b], dist2 float32[N_b]); corr_out holds
+        (idx as float, dist2, 0, ring) like the reference's read-back."""
+        b4 = self.pad_points(points_b)
+        n = len(b4)
+        idx = np.empty(n, dtype=np.uint32)
+        dist = np.empty(n, dtype=np.float32)
+        hint = np.empty(n, dtype=np.float32)
+        check(self._lib.pcp_nn(self._ctx, f32p(b4), n, u32p(idx), f32p(dist), f32p(hint)))
+        self.lens_data = np.array([self.lens_data[0], n, self.lens_data[2], 0]).astype(np.uint32)
+        self.reallocate_out(self.lens_data)
+        self.corr_out[:, 0] = idx
+        self.corr_out[:, 1] = dist
+        self.corr_out[:, 2] = 0
+        self.corr_out[:, 3] = hint
+        return self.corr_out[:, 0].astype(np.uint32), self.corr_out[:, 1].astype(np.float32)
+
+    # ------------------------------------------------------------------ hierarchical sum
+    def hbSum(self, tiles):
+        """prepareDispatchConcurrentHbSum (:630-727) on caller-supplied tiles
+        (n, 8, 8) float32 -> summed (8, 8) tile."""
+        tiles = np.ascontiguousarray(tiles, dtype=np.float32).reshape(-1, 64)
+        out = np.zeros((8, 8), dtype=np.float32)
+        check(self._lib.pcp_hb_sum(self._ctx, f32p(tiles), len(tiles), f32p(out)))
+        return out
+
+    def lsTiles(self, points_b, mode=MODE_POINT, debug=False):
+        """The per-point tiles Hs (N_b, 8, 8) of the LS kernels (what
+        getBufferSubdata(ssbo_Hs) reads in the reference, :399-411)."""
+        b4 = self.pad_points(points_b)
+        self.hs_out = np.zeros((len(b4), 8, 8), dtype=np.float32)
+        check(self._lib.pcp_ls_tiles(self._ctx, f32p(b4), len(b4), int(mode), int(debug), f32p(self.hs_out)))
+        return self.hs_out
+
+    # ------------------------------------------------------------------ device-resident loop
+    def icpRun(self, points_b, mode, iterations, tol=1e-6, full_iter=False, want_points=False, want_hb=False):
+        """One call for the whole iteration loop of full_pt2pt / full_pt2pl
+        (PointcloudIcpContainer.py:84-94, :118-133) on the prepared target.
+        Returns (dx_trace (iters, 6) f32, converged, hb_trace | None, moved points | None)."""
+        b = np.ascontiguousarray(np.asarray(points_b)[:, :3], dtype=np.float64)
+        n = len(b)
+        dx = np.zeros((max(iterations, 1), 6), dtype=np.float32)
+        hb = np.zeros((max(iterations, 1), 8, 8), dtype=np.float32) if want_hb else None
+        out = np.empty_like(b) if want_points else None
+        iters, conv = C.c_int(0), C.c_int(0)
+        check(self._lib.pcp_icp_run(self._ctx, f64p(b), n, int(mode), int(iterations), float(tol), int(full_iter),
+                                    f32p(dx), f32p(hb), C.byref(iters), C.byref(conv), f64p(out)))
+        k = iters.value
+        return dx[:k], bool(conv.value), (hb[:k] if want_hb else None), out
+
+    # ------------------------------------------------------------------ life cycle
+    def synchronize(self):
+        check(self._lib.pcp_synchronize(self._ctx))
+
+    def cleanup(self):
+        """:966-998"""
+        if self._ctx:
+            self._lib.pcp_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.cleanup()
+        except Exception:
+            pass

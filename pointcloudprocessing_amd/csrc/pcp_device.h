@@ -1,0 +1,189 @@
+// Device-side arithmetic shared by the registration kernels.
+//
+// Everything here is strict IEEE float32 evaluated in a fixed order, because
+// comparisons between these values decide which point index wins: the file
+// must be compiled with -ffp-contract=off and without fast-math, so that
+// hipcc neither fuses a*b+c nor replaces sqrtf or '/' by approximations
+// (both are correctly rounded under hipcc's default
+// -fhip-fp32-correctly-rounded-divide-sqrt).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define PCP_BIG 1.23e20f          // FunctionalBase.glsl:146,204
+#define PCP_LIDAR_OFF_Y 0.127f    // 0.254 / 2.0, FunctionalBase.glsl:35-36
+#define PCP_NVAL 27               // 21 upper-triangle JtJ entries + 6 Jte entries
+#define PCP_PSTRIDE 32            // floats per partial record
+
+namespace pcp {
+
+__device__ __forceinline__ float dot4(const float4 a, const float4 b) {
+    float s = a.x * b.x;
+    s = s + a.y * b.y;
+    s = s + a.z * b.z;
+    s = s + a.w * b.w;
+    return s;
+}
+
+__device__ __forceinline__ float dot3(float ax, float ay, float az, float bx, float by, float bz) {
+    float s = ax * bx;
+    s = s + ay * by;
+    s = s + az * bz;
+    return s;
+}
+
+// distsq, FunctionalBase.glsl:106-109
+__device__ __forceinline__ float distsq(const float4 a, const float4 b) {
+    const float4 d = make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w);
+    return dot4(d, d);
+}
+
+// projectSpherePoint / the normalisation inside mcos, FunctionalBase.glsl:34-48.
+// origin is the 4-vector as uploaded ([ox,oy,oz,ox]); the offset is (0, 0.127, 0, 0).
+__device__ __forceinline__ float4 unit_sphere(const float4 p, const float4 o) {
+    float4 v = make_float4(p.x - o.x, (p.y - o.y) - PCP_LIDAR_OFF_Y, p.z - o.z, p.w - o.w);
+    const float len = sqrtf(dot4(v, v));
+    return make_float4(v.x / len, v.y / len, v.z / len, v.w / len);
+}
+
+struct Target {
+    const float4* __restrict__ a;    // target points
+    const float4* __restrict__ ua;   // unit_sphere(a[i])
+    const int2* scan;                // (begin, end_inclusive) per ring, in LDS
+    int n_a;
+    int Z;                           // lens_data.z
+    float4 o;
+};
+
+// binaryScanCircleSearch (FunctionalBase.glsl:69-87) followed by the +-CHECK
+// window of binsearchAndCheck (:142-156) / closestDistinctOnLine
+// (NormalShader.glsl:18-31).  Index arithmetic is the shader's modulo
+// arithmetic with the one integer division hoisted: the absolute midpoint
+// (begin+end)/2 is reduced mod L once, every later step stays inside (-L, 2L)
+// and wraps with a compare.  exclude < 0 disables the 'test != pindex' clause.
+template <int CHECK>
+__device__ __forceinline__ void ring_window(const Target& T, const float4 q, const float4 ref,
+                                            const int beg, const int end, const int exclude,
+                                            int& best, float& mind) {
+    const int L = end - beg + 1;
+    mind = PCP_BIG;
+    if (L == 1) {
+        // runs == 0: the search returns begin + (begin+end)/2 untouched, and all
+        // 2*CHECK window slots are the ring's single point.
+        const int closest = beg + (beg + end) / 2;
+        best = min(closest, T.n_a - 1);
+        const float d = distsq(q, T.a[beg]);
+        if (d < mind && beg != exclude) { mind = d; best = beg; }
+        return;
+    }
+    int idx = ((beg + end) / 2) % L;
+    int half = L / 2;
+    const int runs = 32 - __clz(L - 1);           // exact ceil(log2(L)), L >= 2
+    for (int i = 0; i < runs; ++i) {
+        const int i1 = (idx == 0) ? L - 1 : idx - 1;
+        const int i2 = (idx + 1 == L) ? 0 : idx + 1;
+        const float c1 = dot4(T.ua[beg + i1], ref) + 1.0f;
+        const float c2 = dot4(T.ua[beg + i2], ref) + 1.0f;
+        int t = (c1 > c2) ? idx - half : idx + half;
+        t = (t < 0) ? t + L : ((t >= L) ? t - L : t);
+        idx = t;
+        half = (half + 1) >> 1;
+    }
+    best = beg + idx;
+    if (L >= CHECK) {
+#pragma unroll
+        for (int i = -CHECK; i < CHECK; ++i) {
+            int t = idx + i;
+            t = (t < 0) ? t + L : ((t >= L) ? t - L : t);
+            const int test = beg + t;
+            const float d = distsq(q, T.a[test]);
+            if (d < mind && test != exclude) { mind = d; best = test; }
+        }
+    } else {
+        for (int i = -CHECK; i < CHECK; ++i) {
+            int t = (idx + i + L) % L;
+            if (t < 0) t += L;
+            const int test = beg + t;
+            const float d = distsq(q, T.a[test]);
+            if (d < mind && test != exclude) { mind = d; best = test; }
+        }
+    }
+}
+
+// findClosestPoint, FunctionalBase.glsl:203-231.  hint is corr[id].w, updated in place.
+__device__ __forceinline__ int find_closest(const Target& T, const float4 q, float& hint) {
+    const float4 ref = unit_sphere(q, T.o);
+    float mind = PCP_BIG;
+    int glob = 0;
+    int from = 0, to = T.Z;
+    if (hint != -1.0f) {
+        const int h = (int)hint;
+        from = max(0, h - 2);
+        to = min(T.Z, h + 2);
+    }
+    for (int r = from; r < to; ++r) {
+        const int2 se = T.scan[r];
+        int best;
+        float d;
+        ring_window<10>(T, q, ref, se.x, se.y, -1, best, d);
+        if (d < mind) { mind = d; glob = best; hint = (float)r; }
+    }
+    return glob;
+}
+
+__device__ __forceinline__ float nan0(const float v) { return (v != v) ? 0.0f : v; }
+
+// Upper-triangle index of (i, j), i <= j, in the 27-value record.
+__host__ __device__ constexpr int tri(int i, int j) { return i * 6 - (i * (i - 1)) / 2 + (j - i); }
+
+// LeastSquaresPoint.glsl:87-113.  v[tri(i,j)] = Hs[i][j], v[21+i] = Hs[i][6].
+__device__ __forceinline__ void ls_point_values(const float4 pa, const float4 pb, const float dist,
+                                                float (&v)[PCP_NVAL]) {
+    const float valid = (dist < 0.1f) ? 1.0f : 0.0f;
+    const float e[3] = {pa.x - pb.x, pa.y - pb.y, pa.z - pb.z};
+    const float x = pb.x, y = pb.y, z = pb.z;
+    const float J[3][6] = {{1.0f, 0.0f, 0.0f, 0.0f, -z, y},
+                           {0.0f, 1.0f, 0.0f, z, 0.0f, -x},
+                           {0.0f, 0.0f, 1.0f, -y, x, 0.0f}};
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+#pragma unroll
+        for (int j = i; j < 6; ++j) {
+            float s = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) s = s + J[k][i] * J[k][j];
+            v[tri(i, j)] = nan0(s * valid);
+        }
+        float s = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) s = s + J[k][i] * e[k];
+        v[21 + i] = nan0(s * valid);
+    }
+}
+
+// LeastSquaresPlane.glsl:91-112 with getJ :1-16 (point = the TARGET point).
+__device__ __forceinline__ void ls_plane_values(const float4 pa, const float4 pb, const float4 n,
+                                                const float dist, float (&v)[PCP_NVAL]) {
+    const float valid = (dist < 0.2f) ? 1.0f : 0.0f;
+    const float err = dot3(n.x, n.y, n.z, pa.x - pb.x, pa.y - pb.y, pa.z - pb.z);
+    const float J[6] = {n.x, n.y, n.z,
+                        n.y * pa.z - n.z * pa.y,
+                        n.z * pa.x - n.x * pa.z,
+                        n.x * pa.y - n.y * pa.x};
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+#pragma unroll
+        for (int j = i; j < 6; ++j) v[tri(i, j)] = nan0((J[i] * J[j]) * valid);
+        v[21 + i] = nan0((J[i] * err) * valid);
+    }
+}
+
+// The pairwise tree of ParalellHBSum.glsl:158-164 over the 64 lanes of a wave:
+// after the six steps lane 0 holds exactly sdata[0] of the shader.
+__device__ __forceinline__ float wave_tree_sum(float x) {
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) x = x + __shfl_down(x, s, 64);
+    return x;
+}
+
+}  // namespace pcp

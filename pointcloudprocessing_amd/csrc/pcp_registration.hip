@@ -1,0 +1,775 @@
+// Registration kernels and their C ABI (see include/pcp.h).
+//
+// Data layout in device memory, per context:
+//   a, ua, normals  float4[n_a]   target cloud, its unit-sphere projection, ring normals
+//   b32             float4[n_b]   source cloud as the kernels see it (stepwise calls)
+//   b64             double[3*n_b] source cloud of the device-resident loop (moved in place)
+//   hint            float[n_b]    corr[:,3] of the reference: ring of the last match, -1 = none
+//   partials        float[ceil(n_b/64)][32]  level-1 sums of 64 consecutive points
+//                                 (27 used: 21 upper-triangle JtJ + 6 Jte)
+//   lvl[2]          ping-pong buffers of the upper tree levels
+//   state           IcpState      step to apply next, iteration counters, flags
+// The 8x8 per-point tiles of the reference (Hs, 256 B per point) are only
+// materialised on request (pcp_ls_tiles) -- the fused kernels reduce in registers.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include <vector>
+
+#include "../../include/pcp.h"
+#include "pcp_device.h"
+#include "pcp_host.h"
+
+using namespace pcp;
+
+namespace {
+
+struct IcpState {
+    double R[9];
+    double t[3];
+    int pending;    // (R, t) still has to be applied to the source points
+    int iter;       // dispatches executed so far
+    int done;
+    int converged;
+    int singular;
+    int pad[3];
+};
+
+// ------------------------------------------------------------------------------------------
+// kernels
+// ------------------------------------------------------------------------------------------
+
+__global__ void k_unit(const float4* __restrict__ a, float4* __restrict__ ua, int n, float4 o) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) ua[i] = unit_sphere(a[i], o);
+}
+
+__global__ void k_fill(float* __restrict__ p, int n, float v) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+__device__ __forceinline__ void load_scan(int2* s_scan, const int2* __restrict__ scan, int Z) {
+    for (int i = threadIdx.x; i < Z; i += blockDim.x) s_scan[i] = scan[i];
+    __syncthreads();
+}
+
+// NearestNeighbourScan.glsl:1-35
+__global__ void __launch_bounds__(256)
+k_nn(const float4* __restrict__ a, const float4* __restrict__ ua, const int2* __restrict__ scan,
+     int n_a, int Z, float4 o, const float4* __restrict__ b, int n_b,
+     float* __restrict__ hint, uint32_t* __restrict__ idx, float* __restrict__ dist) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int2* s_scan = reinterpret_cast<int2*>(smem);
+    load_scan(s_scan, scan, Z);
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_b) return;
+    const Target T{a, ua, s_scan, n_a, Z, o};
+    const float4 q = b[i];
+    float h = hint[i];
+    const int nn = find_closest(T, q, h);
+    hint[i] = h;
+    idx[i] = (uint32_t)nn;
+    dist[i] = distsq(q, a[nn]);
+}
+
+// NormalShader.glsl:73-101
+template <int CHECK>
+__device__ __forceinline__ int closest_distinct(const Target& T, const float4 q, const float4 ref,
+                                                int pid, int ring) {
+    const int2 se = T.scan[ring];
+    int best;
+    float d;
+    ring_window<CHECK>(T, q, ref, se.x, se.y, pid, best, d);
+    return best;
+}
+
+__global__ void __launch_bounds__(256)
+k_normals(const float4* __restrict__ a, const float4* __restrict__ ua, const int2* __restrict__ scan,
+          int n_a, int Z, float4 o, float4* __restrict__ normals) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int2* s_scan = reinterpret_cast<int2*>(smem);
+    load_scan(s_scan, scan, Z);
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_a) return;
+    const Target T{a, ua, s_scan, n_a, Z, o};
+    // getScanLineOfPoint, NormalShader.glsl:1-10: first ring that contains the point
+    int ring = -1;
+    for (int r = 0; r < Z; ++r) {
+        const int2 se = s_scan[r];
+        if (se.x <= i && i <= se.y) { ring = r; break; }
+    }
+    if (ring < 0) {  // the shader falls off the end of the function here (undefined)
+        normals[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        return;
+    }
+    const float4 q = a[i];
+    const float4 ref = ua[i];   // == projectSpherePoint(points_a[i])
+    const int on_line = closest_distinct<5>(T, q, ref, i, ring);
+    int nxt;
+    if (ring == Z - 1) {
+        nxt = closest_distinct<5>(T, q, ref, i, ring - 1);
+    } else if (ring == 0) {
+        nxt = closest_distinct<5>(T, q, ref, i, ring + 1);
+    } else {
+        const int above = closest_distinct<5>(T, q, ref, i, ring - 1);
+        const int below = closest_distinct<5>(T, q, ref, i, ring + 1);
+        nxt = (distsq(q, a[below]) < distsq(q, a[above])) ? below : above;
+    }
+    const float4 pl = a[on_line], pn = a[nxt];
+    const float v1x = pl.x - q.x, v1y = pl.y - q.y, v1z = pl.z - q.z;
+    const float v2x = pn.x - q.x, v2y = pn.y - q.y, v2z = pn.z - q.z;
+    const float cx = v1y * v2z - v2y * v1z;
+    const float cy = v1z * v2x - v2z * v1x;
+    const float cz = v1x * v2y - v2x * v1y;
+    const float cl = sqrtf(dot3(cx, cy, cz, cx, cy, cz));
+    float nx = cx / cl, ny = cy / cl, nz = cz / cl;
+    // normalTowardsOrigin, NormalShader.glsl:62-71
+    float tx = o.x - q.x, ty = o.y - q.y, tz = o.z - q.z;
+    const float tl = sqrtf(dot3(tx, ty, tz, tx, ty, tz));
+    tx = tx / tl; ty = ty / tl; tz = tz / tl;
+    const float sgn = (dot3(nx, ny, nz, tx, ty, tz) > dot3(-nx, -ny, -nz, tx, ty, tz)) ? 1.0f : -1.0f;
+    normals[i] = make_float4(nx * sgn, ny * sgn, nz * sgn, 0.0f);
+}
+
+// LeastSquaresPoint.glsl / LeastSquaresPlane.glsl fused with the first level of
+// ParalellHBSum.glsl: one wave = the 64 consecutive points of one shader
+// workgroup; its tree sum goes to partials[wave].
+//   F64SRC: source points are the float64 cloud of the device loop; the step
+//           left pending by the previous iteration is applied first
+//           (apply_iteration_of_ls, PointcloudIcpContainer.py:172-174).
+template <int MODE, bool F64SRC>
+__global__ void __launch_bounds__(256)
+k_ls(const float4* __restrict__ a, const float4* __restrict__ ua, const int2* __restrict__ scan,
+     int n_a, int Z, float4 o, const float4* __restrict__ normals,
+     const float4* __restrict__ b32, double* __restrict__ b64, IcpState* __restrict__ st,
+     int n_b, int debug, float* __restrict__ hint, float* __restrict__ partials,
+     float* __restrict__ tiles) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int2* s_scan = reinterpret_cast<int2*>(smem);
+    if (F64SRC) {
+        if (st->done) return;
+    }
+    load_scan(s_scan, scan, Z);
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool in = i < n_b;
+    float v[PCP_NVAL];
+#pragma unroll
+    for (int k = 0; k < PCP_NVAL; ++k) v[k] = 0.0f;
+    if (in) {
+        float4 q;
+        if (F64SRC) {
+            double px = b64[3 * (size_t)i + 0], py = b64[3 * (size_t)i + 1], pz = b64[3 * (size_t)i + 2];
+            if (st->pending) {
+                const double nx = ((st->R[0] * px + st->R[1] * py) + st->R[2] * pz) - st->t[0];
+                const double ny = ((st->R[3] * px + st->R[4] * py) + st->R[5] * pz) - st->t[1];
+                const double nz = ((st->R[6] * px + st->R[7] * py) + st->R[8] * pz) - st->t[2];
+                px = nx; py = ny; pz = nz;
+                b64[3 * (size_t)i + 0] = px; b64[3 * (size_t)i + 1] = py; b64[3 * (size_t)i + 2] = pz;
+            }
+            q = make_float4((float)px, (float)py, (float)pz, 0.0f);
+        } else {
+            q = b32[i];
+        }
+        const Target T{a, ua, s_scan, n_a, Z, o};
+        int nn;
+        float d;
+        if (debug) {      // debug_info.x >= 1: identity correspondences, LeastSquaresPoint.glsl:78-81
+            nn = i;
+            d = 0.0f;
+        } else {
+            float h = hint[i];
+            nn = find_closest(T, q, h);
+            hint[i] = h;
+            d = distsq(q, a[nn]);
+        }
+        const float4 pa = a[nn];
+        if (MODE == PCP_MODE_POINT) ls_point_values(pa, q, d, v);
+        else ls_plane_values(pa, q, normals[nn], d, v);
+        if (tiles) {
+            float* t = tiles + (size_t)i * 64;
+#pragma unroll
+            for (int r = 0; r < 6; ++r) {
+#pragma unroll
+                for (int c = 0; c < 6; ++c) t[r * 8 + c] = v[r <= c ? tri(r, c) : tri(c, r)];
+                t[r * 8 + 6] = v[21 + r];
+                t[r * 8 + 7] = 0.0f;
+            }
+#pragma unroll
+            for (int k = 48; k < 64; ++k) t[k] = 0.0f;
+        }
+    }
+    const int lane = threadIdx.x & 63;
+    const int wave = i >> 6;               // == shader workgroup id
+    if ((wave << 6) < n_b) {               // wave-uniform
+#pragma unroll
+        for (int k = 0; k < PCP_NVAL; ++k) v[k] = wave_tree_sum(v[k]);
+        if (lane == 0) {
+            float* p = partials + (size_t)wave * PCP_PSTRIDE;
+#pragma unroll
+            for (int k = 0; k < PCP_NVAL; ++k) p[k] = v[k];
+        }
+    }
+}
+
+// 6x6 solve in float64: Gaussian elimination with partial pivoting, the
+// arithmetic order of the host checker's solve6.  Returns false when singular.
+__device__ bool solve6(const float* __restrict__ hb /* 8x8 */, double* x) {
+    double A[6][6];
+    for (int r = 0; r < 6; ++r) {
+        for (int c = 0; c < 6; ++c) A[r][c] = (double)hb[r * 8 + c];
+        x[r] = -(double)hb[r * 8 + 6];
+    }
+    for (int k = 0; k < 6; ++k) {
+        int p = k;
+        for (int r = k + 1; r < 6; ++r)
+            if (fabs(A[r][k]) > fabs(A[p][k])) p = r;
+        if (A[p][k] == 0.0 || A[p][k] != A[p][k]) return false;
+        if (p != k) {
+            for (int c = 0; c < 6; ++c) { const double tmp = A[k][c]; A[k][c] = A[p][c]; A[p][c] = tmp; }
+            const double tmp = x[k]; x[k] = x[p]; x[p] = tmp;
+        }
+        for (int r = k + 1; r < 6; ++r) {
+            const double m = A[r][k] / A[k][k];
+            for (int c = k + 1; c < 6; ++c) A[r][c] = A[r][c] - m * A[k][c];
+            x[r] = x[r] - m * x[k];
+        }
+    }
+    for (int k = 5; k >= 0; --k) {
+        double s = x[k];
+        for (int c = k + 1; c < 6; ++c) s = s - A[k][c] * x[c];
+        x[k] = s / A[k][k];
+    }
+    return true;
+}
+
+__device__ void mm3(const double* A, const double* B, double* C) {
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j)
+            C[i * 3 + j] = (A[i * 3 + 0] * B[0 * 3 + j] + A[i * 3 + 1] * B[1 * 3 + j]) + A[i * 3 + 2] * B[2 * 3 + j];
+}
+
+// PointcloudAlignment.rotation (PointcloudAlignment.py:229-261): Rx @ Ry @ Rz with
+// float32 trig values held in float64 matrices.
+__device__ void rotation_xyz(float xr, float yr, float zr, double* R) {
+    const double cx = (double)(float)cos((double)xr), sx = (double)(float)sin((double)xr);
+    const double cy = (double)(float)cos((double)yr), sy = (double)(float)sin((double)yr);
+    const double cz = (double)(float)cos((double)zr), sz = (double)(float)sin((double)zr);
+    const double Rz[9] = {cz, -sz, 0, sz, cz, 0, 0, 0, 1.0};
+    const double Ry[9] = {cy, 0, sy, 0, 1.0, 0, -sy, 0, cy};
+    const double Rx[9] = {1.0, 0, 0, 0, cx, -sx, 0, sx, cx};
+    double M[9];
+    mm3(Rx, Ry, M);
+    mm3(M, Rz, R);
+}
+
+// Upper levels of the ParalellHBSum tree (ComputeShader.py:682-707) over the
+// level-1 partials, then -- when solve != 0 -- the host half of one iteration:
+// dispatchPointToPoint / dispatchPointToPlane (PointcloudIcpContainer.py:24-29,
+// :47-69).  One block of 1024 threads.
+__global__ void __launch_bounds__(1024)
+k_finish(const float* __restrict__ partials, int n1, float* __restrict__ lvl0, float* __restrict__ lvl1,
+         IcpState* __restrict__ st, float* __restrict__ hb_out, float* __restrict__ dx_out,
+         int solve, int mode, int max_iter, float tol, int full_iter) {
+    if (solve && st->done) return;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int nwaves = blockDim.x >> 6;
+    const float* in = partials;
+    float* out = lvl0;
+    float* other = lvl1;
+    int n = n1;
+    while (n > 1) {
+        const int groups = (n + 63) >> 6;
+        for (int g = wave; g < groups; g += nwaves) {
+            const int src = g * 64 + lane;
+            float v[PCP_NVAL];
+#pragma unroll
+            for (int k = 0; k < PCP_NVAL; ++k) v[k] = (src < n) ? in[(size_t)src * PCP_PSTRIDE + k] : 0.0f;
+#pragma unroll
+            for (int k = 0; k < PCP_NVAL; ++k) v[k] = wave_tree_sum(v[k]);
+            if (lane == 0) {
+#pragma unroll
+                for (int k = 0; k < PCP_NVAL; ++k) out[(size_t)g * PCP_PSTRIDE + k] = v[k];
+            }
+        }
+        __threadfence_block();
+        __syncthreads();
+        in = out;
+        float* tmp = out; out = other; other = tmp;
+        n = groups;
+    }
+    if (threadIdx.x != 0) return;
+    const int it = solve ? st->iter : 0;
+    float* hb = hb_out + (size_t)it * 64;
+    for (int r = 0; r < 8; ++r)
+        for (int c = 0; c < 8; ++c) {
+            float val = 0.0f;
+            if (r < 6 && c < 6) val = in[r <= c ? tri(r, c) : tri(c, r)];
+            else if (r < 6 && c == 6) val = in[21 + r];
+            hb[r * 8 + c] = val;
+        }
+    if (!solve) return;
+    double x[6];
+    if (!solve6(hb, x)) {
+        st->singular = 1;
+        st->done = 1;
+        st->pending = 0;
+        st->iter = it + 1;
+        return;
+    }
+    float dx[6];
+    for (int k = 0; k < 6; ++k) { dx[k] = (float)x[k]; dx_out[(size_t)it * 6 + k] = dx[k]; }
+    st->iter = it + 1;
+    if (mode == PCP_MODE_PLANE && !full_iter) {
+        float s = 0.0f;                       // np.mean(np.abs(delta_x)), float32
+        for (int k = 0; k < 6; ++k) s = s + fabsf(dx[k]);
+        if (s / 6.0f < tol) {
+            st->converged = 1;
+            st->done = 1;
+            st->pending = 0;
+            return;
+        }
+    }
+    rotation_xyz(dx[3], dx[4], dx[5], st->R);
+    st->t[0] = (double)dx[0]; st->t[1] = (double)dx[1]; st->t[2] = (double)dx[2];
+    st->pending = 1;
+    if (it + 1 >= max_iter) st->done = 1;
+}
+
+// Applies the step still pending after the last dispatch.
+__global__ void k_apply_pending(double* __restrict__ b64, int n_b, IcpState* __restrict__ st) {
+    if (!st->pending) return;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_b) return;
+    const double px = b64[3 * (size_t)i + 0], py = b64[3 * (size_t)i + 1], pz = b64[3 * (size_t)i + 2];
+    b64[3 * (size_t)i + 0] = ((st->R[0] * px + st->R[1] * py) + st->R[2] * pz) - st->t[0];
+    b64[3 * (size_t)i + 1] = ((st->R[3] * px + st->R[4] * py) + st->R[5] * pz) - st->t[1];
+    b64[3 * (size_t)i + 2] = ((st->R[6] * px + st->R[7] * py) + st->R[8] * pz) - st->t[2];
+}
+
+__global__ void k_clear_pending(IcpState* __restrict__ st) { st->pending = 0; }
+
+// ParalellHBSum.glsl:127-171, one level.  A wave owns one block of 64 tiles and
+// keeps element `lane` of each of them in a register, so every load is one
+// contiguous 256-byte tile row across the wave and the pairwise tree
+// (s = 32..1: a[t] += a[t+s]) runs in registers without any exchange.
+// Rows 6-7 and column 7 carry no data in the reference; they are written as 0.
+__global__ void __launch_bounds__(256)
+k_hb_level(const float* __restrict__ in, int n, float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int g = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int groups = (n + 63) >> 6;
+    if (g >= groups) return;
+    const bool live = lane < 48 && (lane & 7) != 7;
+    float v[64];
+    const size_t base = (size_t)g * 64;
+#pragma unroll
+    for (int t = 0; t < 64; ++t)
+        v[t] = (live && base + t < (size_t)n) ? in[(base + t) * 64 + lane] : 0.0f;
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) {
+#pragma unroll
+        for (int t = 0; t < s; ++t) v[t] = v[t] + v[t + s];
+    }
+    out[(size_t)g * 64 + lane] = live ? v[0] : 0.0f;
+}
+
+// ------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------
+
+inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+}  // namespace
+
+struct pcp_ctx {
+    int device = 0, max_points = 0, max_scans = 0;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    float4 *a = nullptr, *ua = nullptr, *normals = nullptr, *b32 = nullptr;
+    double* b64 = nullptr;
+    float *hint = nullptr, *nn_dist = nullptr;
+    uint32_t* nn_idx = nullptr;
+    int2* scan = nullptr;
+    float *partials = nullptr, *lvl0 = nullptr, *lvl1 = nullptr;
+    float *hb_trace = nullptr, *dx_trace = nullptr;   // max_iter_cap x 64 / x 6
+    IcpState* state = nullptr;
+    float *tiles = nullptr, *tiles2 = nullptr;        // lazily allocated
+    float4 origin = {0, 0, 0, 0};
+    int n_a = 0, n_b = 0, n_scans = 0;
+    bool have_target = false, have_normals = false;
+    int run_mode = 0, run_max_iter = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    static const int max_iter_cap = 1024;
+};
+
+namespace {
+
+int use(pcp_ctx* c) {
+    if (!c) return pcp_fail("null context");
+    PCP_CHECK(hipSetDevice(c->device));
+    return 0;
+}
+
+int ensure_tiles(pcp_ctx* c) {
+    if (c->tiles) return 0;
+    PCP_CHECK(hipMalloc(&c->tiles, (size_t)c->max_points * 64 * sizeof(float)));
+    const int g1 = cdiv(c->max_points, 64);
+    PCP_CHECK(hipMalloc(&c->tiles2, (size_t)(g1 + cdiv(g1, 64)) * 64 * sizeof(float)));
+    return 0;
+}
+
+size_t scan_smem(const pcp_ctx* c) { return (size_t)c->n_scans * sizeof(int2); }
+
+int upload_b32(pcp_ctx* c, const float* b_xyzw, int n_b) {
+    if (!c->have_target) return pcp_fail("no target: call pcp_set_target first");
+    if (!b_xyzw) return pcp_fail("null source points");
+    if (n_b < 1 || n_b > c->max_points) return pcp_fail("n_b = %d outside [1, %d]", n_b, c->max_points);
+    c->n_b = n_b;
+    PCP_CHECK(hipMemcpyAsync(c->b32, b_xyzw, (size_t)n_b * sizeof(float4), hipMemcpyHostToDevice, c->stream));
+    return 0;
+}
+
+int launch_ls(pcp_ctx* c, int mode, bool f64src, int debug, float* tiles) {
+    const int n_b = c->n_b;
+    const dim3 grid(cdiv(n_b, 256)), block(256);
+    const size_t sm = scan_smem(c);
+    if (mode == PCP_MODE_PLANE && !c->have_normals) return pcp_fail("plane mode needs pcp_normals after pcp_set_target");
+    if (debug && n_b > c->n_a) return pcp_fail("identity correspondences need n_b <= n_a");
+#define PCP_LS_ARGS c->a, c->ua, c->scan, c->n_a, c->n_scans, c->origin, c->normals, c->b32, c->b64, c->state, \
+                    n_b, debug, c->hint, c->partials, tiles
+    if (mode == PCP_MODE_POINT) {
+        if (f64src) hipLaunchKernelGGL((k_ls<PCP_MODE_POINT, true>), grid, block, sm, c->stream, PCP_LS_ARGS);
+        else hipLaunchKernelGGL((k_ls<PCP_MODE_POINT, false>), grid, block, sm, c->stream, PCP_LS_ARGS);
+    } else if (mode == PCP_MODE_PLANE) {
+        if (f64src) hipLaunchKernelGGL((k_ls<PCP_MODE_PLANE, true>), grid, block, sm, c->stream, PCP_LS_ARGS);
+        else hipLaunchKernelGGL((k_ls<PCP_MODE_PLANE, false>), grid, block, sm, c->stream, PCP_LS_ARGS);
+    } else {
+        return pcp_fail("unknown mode %d", mode);
+    }
+#undef PCP_LS_ARGS
+    PCP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int launch_finish(pcp_ctx* c, int solve, int mode, int max_iter, float tol, int full_iter) {
+    hipLaunchKernelGGL(k_finish, dim3(1), dim3(1024), 0, c->stream, c->partials, cdiv(c->n_b, 64),
+                       c->lvl0, c->lvl1, c->state, c->hb_trace, c->dx_trace, solve, mode, max_iter, tol,
+                       full_iter);
+    PCP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int ls_stepwise(pcp_ctx* c, const float* b_xyzw, int n_b, int mode, int debug, float* hb, float* tiles_host) {
+    if (int e = use(c)) return e;
+    if (int e = upload_b32(c, b_xyzw, n_b)) return e;
+    float* tiles = nullptr;
+    if (tiles_host) {
+        if (int e = ensure_tiles(c)) return e;
+        tiles = c->tiles;
+    }
+    if (int e = launch_ls(c, mode, false, debug, tiles)) return e;
+    if (hb) {
+        if (int e = launch_finish(c, 0, mode, 0, 0.f, 0)) return e;
+        PCP_CHECK(hipMemcpyAsync(hb, c->hb_trace, 64 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    }
+    if (tiles_host)
+        PCP_CHECK(hipMemcpyAsync(tiles_host, tiles, (size_t)n_b * 64 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    PCP_CHECK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------
+
+extern "C" {
+
+int pcp_version(void) { return 1; }
+
+int pcp_device_count(int* count) {
+    if (!count) return pcp_fail("null count");
+    PCP_CHECK(hipGetDeviceCount(count));
+    return 0;
+}
+
+int pcp_create(int device, int max_points, int max_scans, pcp_ctx** out) {
+    if (!out) return pcp_fail("null out pointer");
+    *out = nullptr;
+    if (max_points < 1 || max_points > (1 << 24))
+        return pcp_fail("max_points = %d outside [1, 2^24] (indices travel as float32 in the reference)", max_points);
+    if (max_scans < 1 || max_scans > 4096) return pcp_fail("max_scans = %d outside [1, 4096]", max_scans);
+    int ndev = 0;
+    PCP_CHECK(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) return pcp_fail("device %d not present (%d visible)", device, ndev);
+    PCP_CHECK(hipSetDevice(device));
+    pcp_ctx* c = new pcp_ctx();
+    c->device = device;
+    c->max_points = max_points;
+    c->max_scans = max_scans;
+    const size_t n = (size_t)max_points;
+    const int n1 = cdiv(max_points, 64), n2 = cdiv(n1, 64);
+    hipError_t e = hipSuccess;
+    auto A = [&](void** p, size_t bytes) { if (e == hipSuccess) e = hipMalloc(p, bytes); };
+    A((void**)&c->a, n * sizeof(float4));
+    A((void**)&c->ua, n * sizeof(float4));
+    A((void**)&c->normals, n * sizeof(float4));
+    A((void**)&c->b32, n * sizeof(float4));
+    A((void**)&c->b64, n * 3 * sizeof(double));
+    A((void**)&c->hint, n * sizeof(float));
+    A((void**)&c->nn_dist, n * sizeof(float));
+    A((void**)&c->nn_idx, n * sizeof(uint32_t));
+    A((void**)&c->scan, (size_t)max_scans * sizeof(int2));
+    A((void**)&c->partials, (size_t)n1 * PCP_PSTRIDE * sizeof(float));
+    A((void**)&c->lvl0, (size_t)n2 * PCP_PSTRIDE * sizeof(float));
+    A((void**)&c->lvl1, (size_t)n2 * PCP_PSTRIDE * sizeof(float));
+    A((void**)&c->hb_trace, (size_t)pcp_ctx::max_iter_cap * 64 * sizeof(float));
+    A((void**)&c->dx_trace, (size_t)pcp_ctx::max_iter_cap * 6 * sizeof(float));
+    A((void**)&c->state, sizeof(IcpState));
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreate(&c->ev0);
+    if (e == hipSuccess) e = hipEventCreate(&c->ev1);
+    if (e != hipSuccess) {
+        pcp_fail("pcp_create: %s", hipGetErrorString(e));
+        pcp_destroy(c);
+        return 1;
+    }
+    c->stream = c->own_stream;
+    *out = c;
+    return 0;
+}
+
+int pcp_destroy(pcp_ctx* c) {
+    if (!c) return 0;
+    (void)hipSetDevice(c->device);
+    if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
+    void* bufs[] = {c->a, c->ua, c->normals, c->b32, c->b64, c->hint, c->nn_dist, c->nn_idx, c->scan,
+                    c->partials, c->lvl0, c->lvl1, c->hb_trace, c->dx_trace, c->state, c->tiles, c->tiles2};
+    for (void* p : bufs)
+        if (p) (void)hipFree(p);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+    return 0;
+}
+
+int pcp_set_stream(pcp_ctx* c, void* hip_stream) {
+    if (!c) return pcp_fail("null context");
+    c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    return 0;
+}
+
+int pcp_synchronize(pcp_ctx* c) {
+    if (int e = use(c)) return e;
+    PCP_CHECK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int pcp_reset_hints(pcp_ctx* c) {
+    if (int e = use(c)) return e;
+    hipLaunchKernelGGL(k_fill, dim3(cdiv(c->max_points, 256)), dim3(256), 0, c->stream, c->hint, c->max_points, -1.0f);
+    PCP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int pcp_prepare_resident(pcp_ctx* c, int with_normals) {
+    if (int e = use(c)) return e;
+    if (!c->have_target) return pcp_fail("no target: call pcp_set_target first");
+    hipLaunchKernelGGL(k_unit, dim3(cdiv(c->n_a, 256)), dim3(256), 0, c->stream, c->a, c->ua, c->n_a, c->origin);
+    PCP_CHECK(hipGetLastError());
+    if (int e = pcp_reset_hints(c)) return e;
+    if (with_normals) {
+        if (c->n_scans < 2) return pcp_fail("normals need at least 2 scan lines");
+        hipLaunchKernelGGL(k_normals, dim3(cdiv(c->n_a, 256)), dim3(256), scan_smem(c), c->stream, c->a, c->ua,
+                           c->scan, c->n_a, c->n_scans, c->origin, c->normals);
+        PCP_CHECK(hipGetLastError());
+        c->have_normals = true;
+    }
+    return 0;
+}
+
+int pcp_set_target(pcp_ctx* c, const float* a_xyzw, int n_a, const uint32_t* scan_lines, int n_scans,
+                   const float* origin4) {
+    if (int e = use(c)) return e;
+    if (!a_xyzw || !scan_lines || !origin4) return pcp_fail("null argument");
+    if (n_a < 1 || n_a > c->max_points) return pcp_fail("n_a = %d outside [1, %d]", n_a, c->max_points);
+    // the reference overflows its scan-line SSBO here and re-raises the GL error (ComputeShader.py:506-512)
+    if (n_scans < 1 || n_scans > c->max_scans)
+        return pcp_fail("%d scan lines do not fit maxScans = %d", n_scans, c->max_scans);
+    std::vector<int2> lines((size_t)n_scans);
+    for (int i = 0; i < n_scans; ++i) {
+        const uint32_t b = scan_lines[4 * i + 0], e = scan_lines[4 * i + 1];
+        if (b > e || e >= (uint32_t)n_a)
+            return pcp_fail("scan line %d = (%u, %u) outside a cloud of %d points", i, b, e, n_a);
+        lines[i] = make_int2((int)b, (int)e);
+    }
+    c->have_target = false;
+    c->have_normals = false;
+    PCP_CHECK(hipMemcpyAsync(c->a, a_xyzw, (size_t)n_a * sizeof(float4), hipMemcpyHostToDevice, c->stream));
+    PCP_CHECK(hipMemcpyAsync(c->scan, lines.data(), lines.size() * sizeof(int2), hipMemcpyHostToDevice, c->stream));
+    PCP_CHECK(hipStreamSynchronize(c->stream));   // `lines` dies with this frame
+    c->origin = make_float4(origin4[0], origin4[1], origin4[2], origin4[3]);
+    c->n_a = n_a;
+    c->n_scans = n_scans;
+    c->have_target = true;
+    return pcp_prepare_resident(c, 0);
+}
+
+int pcp_normals(pcp_ctx* c, float* out_normals) {
+    if (int e = use(c)) return e;
+    if (!c->have_target) return pcp_fail("no target: call pcp_set_target first");
+    if (c->n_scans < 2) return pcp_fail("normals need at least 2 scan lines");
+    hipLaunchKernelGGL(k_normals, dim3(cdiv(c->n_a, 256)), dim3(256), scan_smem(c), c->stream, c->a, c->ua, c->scan,
+                       c->n_a, c->n_scans, c->origin, c->normals);
+    PCP_CHECK(hipGetLastError());
+    c->have_normals = true;
+    if (out_normals) {
+        PCP_CHECK(hipMemcpyAsync(out_normals, c->normals, (size_t)c->n_a * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
+        PCP_CHECK(hipStreamSynchronize(c->stream));
+    }
+    return 0;
+}
+
+int pcp_nn(pcp_ctx* c, const float* b_xyzw, int n_b, uint32_t* idx, float* dist2, float* hint_out) {
+    if (int e = use(c)) return e;
+    if (!idx || !dist2) return pcp_fail("null output");
+    if (int e = upload_b32(c, b_xyzw, n_b)) return e;
+    hipLaunchKernelGGL(k_nn, dim3(cdiv(n_b, 256)), dim3(256), scan_smem(c), c->stream, c->a, c->ua, c->scan, c->n_a,
+                       c->n_scans, c->origin, c->b32, n_b, c->hint, c->nn_idx, c->nn_dist);
+    PCP_CHECK(hipGetLastError());
+    PCP_CHECK(hipMemcpyAsync(idx, c->nn_idx, (size_t)n_b * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    PCP_CHECK(hipMemcpyAsync(dist2, c->nn_dist, (size_t)n_b * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    if (hint_out)
+        PCP_CHECK(hipMemcpyAsync(hint_out, c->hint, (size_t)n_b * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    PCP_CHECK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int pcp_ls_point(pcp_ctx* c, const float* b_xyzw, int n_b, int debug, float* hb) {
+    if (!hb) return pcp_fail("null output");
+    return ls_stepwise(c, b_xyzw, n_b, PCP_MODE_POINT, debug, hb, nullptr);
+}
+
+int pcp_ls_plane(pcp_ctx* c, const float* b_xyzw, int n_b, float* hb) {
+    if (!hb) return pcp_fail("null output");
+    return ls_stepwise(c, b_xyzw, n_b, PCP_MODE_PLANE, 0, hb, nullptr);
+}
+
+int pcp_ls_tiles(pcp_ctx* c, const float* b_xyzw, int n_b, int mode, int debug, float* tiles) {
+    if (!tiles) return pcp_fail("null output");
+    return ls_stepwise(c, b_xyzw, n_b, mode, debug, nullptr, tiles);
+}
+
+int pcp_hb_sum_dev(pcp_ctx* c, const float* tiles_dev, int n, float* scratch_dev, float* out_dev) {
+    if (int e = use(c)) return e;
+    if (!tiles_dev || !scratch_dev || !out_dev) return pcp_fail("null argument");
+    if (n < 1) return pcp_fail("n = %d: nothing to sum", n);
+    // ComputeShader.py:682-707: levels ping-pong between two buffers until one block is left.
+    // Level 1 writes g1 = ceil(n/64) tiles to scratch[0, g1), level 2 writes ceil(g1/64) tiles
+    // behind them, level 3 reuses the front, and so on.
+    const int g1 = cdiv(n, 64);
+    float* region[2] = {scratch_dev, scratch_dev + (size_t)g1 * 64};
+    const float* in = tiles_dev;
+    int cur = n;
+    for (int level = 0;; ++level) {
+        const int groups = cdiv(cur, 64);
+        float* dst = (groups == 1) ? out_dev : region[level & 1];
+        hipLaunchKernelGGL(k_hb_level, dim3(cdiv(groups, 4)), dim3(256), 0, c->stream, in, cur, dst);
+        PCP_CHECK(hipGetLastError());
+        if (groups == 1) break;
+        in = dst;
+        cur = groups;
+    }
+    return 0;
+}
+
+int pcp_hb_sum(pcp_ctx* c, const float* tiles, int n, float* out) {
+    if (int e = use(c)) return e;
+    if (!tiles || !out) return pcp_fail("null argument");
+    if (n < 1 || n > c->max_points) return pcp_fail("n = %d outside [1, %d]", n, c->max_points);
+    if (int e = ensure_tiles(c)) return e;
+    PCP_CHECK(hipMemcpyAsync(c->tiles, tiles, (size_t)n * 64 * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    if (int e = pcp_hb_sum_dev(c, c->tiles, n, c->tiles2, c->hb_trace)) return e;
+    PCP_CHECK(hipMemcpyAsync(out, c->hb_trace, 64 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    PCP_CHECK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int pcp_upload_source(pcp_ctx* c, const double* b_xyz, int n_b) {
+    if (int e = use(c)) return e;
+    if (!b_xyz) return pcp_fail("null source points");
+    if (n_b < 1 || n_b > c->max_points) return pcp_fail("n_b = %d outside [1, %d]", n_b, c->max_points);
+    c->n_b = n_b;
+    PCP_CHECK(hipMemcpyAsync(c->b64, b_xyz, (size_t)n_b * 3 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    return 0;
+}
+
+int pcp_icp_launch(pcp_ctx* c, int mode, int max_iter, float tol, int full_iter) {
+    if (int e = use(c)) return e;
+    if (!c->have_target) return pcp_fail("no target: call pcp_set_target first");
+    if (c->n_b < 1) return pcp_fail("no source: call pcp_upload_source first");
+    if (max_iter < 0 || max_iter > pcp_ctx::max_iter_cap)
+        return pcp_fail("max_iter = %d outside [0, %d]", max_iter, pcp_ctx::max_iter_cap);
+    if (mode != PCP_MODE_POINT && mode != PCP_MODE_PLANE) return pcp_fail("unknown mode %d", mode);
+    PCP_CHECK(hipMemsetAsync(c->state, 0, sizeof(IcpState), c->stream));
+    c->run_mode = mode;
+    c->run_max_iter = max_iter;
+    for (int it = 0; it < max_iter; ++it) {
+        if (int e = launch_ls(c, mode, true, 0, nullptr)) return e;
+        if (int e = launch_finish(c, 1, mode, max_iter, tol, full_iter)) return e;
+    }
+    hipLaunchKernelGGL(k_apply_pending, dim3(cdiv(c->n_b, 256)), dim3(256), 0, c->stream, c->b64, c->n_b, c->state);
+    PCP_CHECK(hipGetLastError());
+    hipLaunchKernelGGL(k_clear_pending, dim3(1), dim3(1), 0, c->stream, c->state);
+    PCP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int pcp_icp_fetch(pcp_ctx* c, float* dx_trace, float* hb_trace, int* iters, int* converged, double* b_out) {
+    if (int e = use(c)) return e;
+    IcpState st;
+    PCP_CHECK(hipMemcpyAsync(&st, c->state, sizeof(IcpState), hipMemcpyDeviceToHost, c->stream));
+    PCP_CHECK(hipStreamSynchronize(c->stream));
+    const int n = st.iter;
+    if (dx_trace && n > 0)
+        PCP_CHECK(hipMemcpyAsync(dx_trace, c->dx_trace, (size_t)n * 6 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    if (hb_trace && n > 0)
+        PCP_CHECK(hipMemcpyAsync(hb_trace, c->hb_trace, (size_t)n * 64 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    if (b_out)
+        PCP_CHECK(hipMemcpyAsync(b_out, c->b64, (size_t)c->n_b * 3 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    PCP_CHECK(hipStreamSynchronize(c->stream));
+    if (iters) *iters = n;
+    if (converged) *converged = st.converged;
+    if (st.singular) return pcp_fail("singular normal equations at iteration %d", n - 1);
+    return 0;
+}
+
+int pcp_icp_run(pcp_ctx* c, const double* b_xyz, int n_b, int mode, int max_iter, float tol, int full_iter,
+                float* dx_trace, float* hb_trace, int* iters, int* converged, double* b_out) {
+    if (int e = pcp_upload_source(c, b_xyz, n_b)) return e;
+    if (int e = pcp_reset_hints(c)) return e;
+    if (int e = pcp_icp_launch(c, mode, max_iter, tol, full_iter)) return e;
+    return pcp_icp_fetch(c, dx_trace, hb_trace, iters, converged, b_out);
+}
+
+int pcp_timer_start(pcp_ctx* c) {
+    if (int e = use(c)) return e;
+    PCP_CHECK(hipEventRecord(c->ev0, c->stream));
+    return 0;
+}
+
+int pcp_timer_stop(pcp_ctx* c, float* ms) {
+    if (int e = use(c)) return e;
+    if (!ms) return pcp_fail("null output");
+    PCP_CHECK(hipEventRecord(c->ev1, c->stream));
+    PCP_CHECK(hipEventSynchronize(c->ev1));
+    PCP_CHECK(hipEventElapsedTime(ms, c->ev0, c->ev1));
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,180 @@
+"""Host driver of the registration path with the reference's call surface
+(PointcloudIcpContainer.py, class PointcloudIcpContainer; file:line citations
+point there).  The per-iteration methods call the stepwise kernels exactly as
+the reference does; full_pt2pt / full_pt2pl run the whole loop on the device
+(ComputeShader.icpRun) and only replay the 6-vector steps on the 1000-point
+tracking grid on the host.
+"""
+import numpy as np
+
+from .alignment import PointcloudAlignment
+from .compute_shader import MODE_PLANE, MODE_POINT
+
+
+class PointcloudIcpContainer:
+
+    def __init__(self, computeShader, pointcloudAlignment=None):
+        self.compute = computeShader
+        self.pointcloudAlignment = pointcloudAlignment
+
+    # ------------------------------------------------------------------ scan lines (:349-392)
+    def sphereProjectPont(self, point, origin):
+        off = np.array([0, 0.254 / 2, 0])
+        v = point - origin - off
+        return v / np.linalg.norm(v)
+
+    def sphereProjectPoints(self, np_points, origin):
+        off = np.array([0, 0.254 / 2, 0])
+        v = np_points - origin - off
+        return v / np.linalg.norm(v, axis=1)[:, np.newaxis]
+
+    def getScanLines(self, pts, origin):
+        """:362-392 -- a ring ends where the azimuth wraps; the points after the
+        last wrap belong to no ring."""
+        proj = self.sphereProjectPoints(pts, origin)
+        angs = np.arctan2(proj[:, 2], proj[:, 0])
+        angs[angs < 0] += np.pi * 2
+        wraps = np.abs(angs[1:] - angs[:-1]) > 6
+        ends = np.nonzero(wraps)[0]
+        scan_lines, begin = [], 0
+        for e in ends:
+            scan_lines.append((begin, e))
+            begin = e + 1
+        return scan_lines
+
+    # ------------------------------------------------------------------ stepwise protocol
+    def preparePointToPoint(self, points_a, origin, points_b):
+        """:20-22"""
+        self.compute.prepareLS(points_a, self.getScanLines(points_a, origin), points_b, origin, False)
+
+    def dispatchPointToPoint(self, points_b):
+        """:24-29"""
+        H, b = self.compute.dispatchLS(points_b)
+        delta_x = np.linalg.solve(H, -b)
+        t, r = delta_x[:3], delta_x[3:]
+        return t, PointcloudAlignment.rotation(r[0], r[1], r[2])
+
+    def preparePointToPlane(self, points_a, origin, points_b):
+        """:31-39"""
+        self.compute.preparePointPlane(points_a, self.getScanLines(points_a, origin), points_b, origin, False)
+
+    def dispatchPointToPlane(self, points_b):
+        """:47-69 -- a singular system raises LinAlgError (the reference prints
+        and then fails on the unbound delta_x)."""
+        H, b = self.compute.dispatchPointPlane(points_b)
+        delta_x = np.linalg.solve(H, -b)
+        t, r = delta_x[:3], delta_x[3:]
+        return t, PointcloudAlignment.rotation(r[0], r[1], r[2]), np.mean(np.abs(delta_x))
+
+    def initLS(self, aligned, to_align, origin):
+        """:146-149"""
+        self.compute.prepareLS(aligned, self.getScanLines(aligned, origin), to_align, origin)
+
+    def prepareNNS(self, points_a, origin, points_b):
+        """:151-153"""
+        self.compute.prepareNNS(points_a, self.getScanLines(points_a, origin), points_b, origin)
+
+    def dispatchNNS(self, points_b):
+        """:155-156"""
+        return self.compute.dispatchNNS(points_b)
+
+    def getHsBsCompute(self, to_align):
+        """:178-179"""
+        return self.compute.dispatchLS(to_align)
+
+    def apply_iteration_of_ls(self, to_align, t, R):
+        """:172-174"""
+        return (R @ to_align.T).T - t
+
+    def applyIcpStep(self, np_points, R, t):
+        """:320-322"""
+        return (R @ np_points.T).T + t
+
+    # ------------------------------------------------------------------ full loops
+    def _replay(self, dx_trace, applied):
+        grid = self.getUniformGrid(10)
+        for dx in dx_trace[:applied]:
+            R = PointcloudAlignment.rotation(dx[3], dx[4], dx[5])
+            grid = self.applyIcpStep(grid, R, dx[:3])
+        R_opt, t_opt = self.uniform_optimal_icp(grid, self.getUniformGrid(10))
+        return t_opt, R_opt
+
+    def full_pt2pt(self, aligned, to_align, origin, iterations=20, renderer=None):
+        """:71-100 -> (t_opt, R_opt); exactly `iterations` steps."""
+        self.preparePointToPoint(aligned, origin, to_align)
+        if renderer is not None:
+            return self._full_stepwise(to_align, iterations, renderer, plane=False, full_iter=True)
+        dx, _, _, _ = self.compute.icpRun(to_align, MODE_POINT, iterations)
+        return self._replay(dx, len(dx))
+
+    def full_pt2pl(self, aligned, to_align, origin, iterations=20, renderer=None, full_iter=False):
+        """:103-144 -> (t_opt, R_opt); stops when mean|dx| < 1e-6 unless full_iter."""
+        self.preparePointToPlane(aligned, origin, to_align)
+        if renderer is not None:
+            return self._full_stepwise(to_align, iterations, renderer, plane=True, full_iter=full_iter)
+        dx, converged, _, _ = self.compute.icpRun(to_align, MODE_PLANE, iterations, tol=1e-6, full_iter=full_iter)
+        return self._replay(dx, len(dx) - 1 if converged else len(dx))
+
+    def _full_stepwise(self, to_align, iterations, renderer, plane, full_iter):
+        """The reference's host loop, one dispatch per iteration, for callers
+        that want to draw every intermediate cloud."""
+        grid = self.getUniformGrid(10)
+        prev = renderer.addPoints(to_align, np.array([0, 0, 255]))
+        for _ in range(iterations):
+            if plane:
+                t, R, delta = self.dispatchPointToPlane(to_align)
+                if delta < 1e-6 and not full_iter:
+                    break
+            else:
+                t, R = self.dispatchPointToPoint(to_align)
+            to_align = self.apply_iteration_of_ls(to_align, t, R)
+            if prev is not None:
+                renderer.freePoints(prev)
+            prev = renderer.addPoints(to_align)
+            grid = self.applyIcpStep(grid, R, t)
+        if plane and prev is not None:
+            renderer.freePoints(prev)
+        R_opt, t_opt = self.uniform_optimal_icp(grid, self.getUniformGrid(10))
+        return t_opt, R_opt
+
+    # ------------------------------------------------------------------ pose extraction (:333-347, :429-461)
+    def uniform_optimal_icp(self, grid1, grid2):
+        mean_ref = np.mean(grid1, axis=0)
+        mean_other = np.mean(grid2, axis=0)
+        W = (grid1 - mean_ref).T @ (grid2 - mean_other)
+        U, S, Vh = np.linalg.svd(W)
+        R = U @ Vh
+        return R, mean_ref - R @ mean_other
+
+    def getUniformGrid(self, pointsPerAxis):
+        ax = np.linspace(-1, 1, pointsPerAxis)
+        X, Y, Z = np.meshgrid(ax, ax, ax, indexing='ij')
+        return np.vstack([X.ravel(), Y.ravel(), Z.ravel()]).T
+
+    def getUniformShape(self):
+        g = self.getUniformGrid(10)
+        return np.vstack([g, g + np.array([1, 0, 0]) * 5, g + np.array([0, 1, 0]) * 5, g + np.array([1, 1, 1]) * 5])
+
+    # ------------------------------------------------------------------ NumPy J / H / b (:181-205, :267-287)
+    def getJ(self, points):
+        n = points.shape[0]
+        x, y, z = points[:, 0], points[:, 1], points[:, 2]
+        J = np.zeros((n, 3, 6), dtype=np.float32)
+        J[:, 0, 0] = 1; J[:, 0, 4] = -z; J[:, 0, 5] = y
+        J[:, 1, 1] = 1; J[:, 1, 3] = z; J[:, 1, 5] = -x
+        J[:, 2, 2] = 1; J[:, 2, 3] = -y; J[:, 2, 4] = x
+        return J
+
+    def getHsBsNumpy(self, aligned, to_align):
+        J = self.getJ(to_align)
+        J_T = J.swapaxes(1, 2)
+        e = (aligned - to_align)[:, :, np.newaxis]
+        return np.matmul(J_T, J), np.matmul(J_T, e).squeeze(-1)
+
+    def sumHsBsNumpy(self, Hs, Bs):
+        return np.sum(Hs, axis=0), np.sum(Bs, axis=0)
+
+    def icp_step_LS_vector(self, aligned, to_align):
+        H, b = self.sumHsBsNumpy(*self.getHsBsNumpy(aligned, to_align))
+        delta_x = np.linalg.solve(H, -b)
+        return delta_x[:3], delta_x[3:]

@@ -1,0 +1,226 @@
+"""Parity of the HIP registration kernels (through the C ABI, via the
+ComputeShader-compatible class) with the NumPy restatement in oracle/.
+
+Bar: bit-exact for indices, distances, ring hints, normals, per-point tiles and
+the tree-summed H/b (all float32 with a fixed evaluation order); the
+device-resident ICP loop is held to 1e-5 rotation / 1e-4 m translation and, in
+practice, is bit-equal step by step.
+"""
+import numpy as np
+import pytest
+
+from oracle import np_oracle as O
+from pointcloudprocessing_amd import MODE_PLANE, MODE_POINT, PointcloudIcpContainer
+from tests._data import bits, golden, kitti_pair, small_pair
+
+pytestmark = pytest.mark.gpu
+ORIGIN = np.zeros(3)
+
+
+def _oracle_state(a, origin, kind):
+    st = O.RingIcp(100)
+    lines = O.get_scan_lines(a, origin)
+    {"nns": st.prepare_nns, "ls": st.prepare_ls, "plane": st.prepare_plane}[kind](a, lines, origin)
+    return st, lines
+
+
+# ------------------------------------------------------------------------------ NN (a-2)
+@pytest.mark.parametrize("origin", [np.zeros(3), np.array([0.3, -0.1, 0.25])])
+def test_nn_small_matches_oracle_bitwise(compute, origin):
+    a, b = small_pair()
+    st, lines = _oracle_state(a, origin, "nns")
+    compute.prepareNNS(a, lines, b, origin)
+    for call in range(3):          # first call scans all 100 rings, later ones follow the hints
+        idx, dist = compute.dispatchNNS(b)
+        ridx, rdist = st.dispatch_nns(b)
+        assert np.array_equal(idx, ridx), f"call {call}"
+        assert np.array_equal(bits(dist), bits(rdist)), f"call {call}"
+        assert np.array_equal(bits(compute.corr_out[:, 3]), bits(st.hint)), f"call {call}"
+        b = b + np.array([0.01, 0.0, -0.005])
+
+
+def test_nn_kitti_matches_golden(compute):
+    a, b = kitti_pair()
+    g = golden("oracle_kitti.npz")
+    icp = PointcloudIcpContainer(compute)
+    icp.prepareNNS(a, ORIGIN, b)
+    idx, dist = icp.dispatchNNS(b)
+    assert np.array_equal(idx, g["nn_idx"])
+    assert np.array_equal(bits(dist), bits(g["nn_dist"]))
+    assert np.array_equal(compute.corr_out[:, 3].astype(np.int8), g["nn_hint"])
+    idx2, dist2 = icp.dispatchNNS(b)   # hint-guided second pass
+    assert O_sha(idx2) == str(g["nn2_idx_sha"])
+    assert O_sha(dist2) == str(g["nn2_dist_sha"])
+
+
+def test_nn_kitti_nonzero_origin_matches_golden(compute):
+    a, b = kitti_pair()
+    g = golden("oracle_kitti.npz")
+    o = golden("ref_kat.npz")["scan_origin"]
+    icp = PointcloudIcpContainer(compute)
+    icp.prepareNNS(a, o, b[::8])
+    idx, dist = icp.dispatchNNS(b[::8])
+    assert np.array_equal(idx, g["nn_o_idx"])
+    assert np.array_equal(bits(dist), bits(g["nn_o_dist"]))
+
+
+def O_sha(a):
+    import hashlib
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+# ------------------------------------------------------------------------------ normals (a-3)
+def test_normals_small_matches_oracle_bitwise(compute):
+    a, _ = small_pair()
+    lines = O.get_scan_lines(a, ORIGIN)
+    compute.prepareDispatchNormals(a, lines, ORIGIN)
+    ref = O.normals(O.pad_points(a), O.origin4(ORIGIN), O.pad_scan_lines(lines).astype(np.int64), 100)
+    assert compute.normals_out_a.shape == (len(a), 4)
+    assert np.array_equal(bits(compute.normals_out_a), bits(ref))
+
+
+def test_normals_kitti_matches_golden(compute):
+    a, _ = kitti_pair()
+    g = golden("oracle_kitti.npz")
+    lines = O.get_scan_lines(a, ORIGIN)
+    compute.prepareDispatchNormals(a, lines, ORIGIN)
+    assert np.array_equal(bits(compute.normals_out_a[::16]), bits(g["normals_sub"]))
+    assert O_sha(compute.normals_out_a) == str(g["normals_sha"])
+
+
+# ------------------------------------------------------------------------------ LS tiles + tree sum (a-4, a-5, a-6)
+def test_ls_point_tiles_and_sum_match_oracle_bitwise(compute):
+    a, b = small_pair()
+    st, lines = _oracle_state(a, ORIGIN, "ls")
+    compute.prepareLS(a, lines, b, ORIGIN)
+    tiles = compute.lsTiles(b, MODE_POINT).copy()
+    nn, d = st._nn(O.pad_points(b))
+    ref = O.ls_point_tiles(st.a4, O.pad_points(b), nn, d)
+    assert np.array_equal(bits(tiles), bits(ref))
+    # second dispatch (hints now set on both sides) through the fused sum
+    H, bb = compute.dispatchLS(b)
+    rH, rb = st.dispatch_ls(b)
+    assert np.array_equal(bits(H), bits(rH)) and np.array_equal(bits(bb), bits(rb))
+
+
+def test_ls_plane_tiles_and_sum_match_oracle_bitwise(compute):
+    a, b = small_pair()
+    st, lines = _oracle_state(a, ORIGIN, "plane")
+    compute.preparePointPlane(a, lines, b, ORIGIN)
+    tiles = compute.lsTiles(b, MODE_PLANE).copy()
+    nn, d = st._nn(O.pad_points(b))
+    ref = O.ls_plane_tiles(st.a4, O.pad_points(b), st.normals_a, nn, d)
+    assert np.array_equal(bits(tiles), bits(ref))
+    H, bb = compute.dispatchPointPlane(b)
+    rH, rb = st.dispatch_plane(b)
+    assert np.array_equal(bits(H), bits(rH)) and np.array_equal(bits(bb), bits(rb))
+
+
+def test_identity_correspondence_grid_matches_reference_numpy(compute):
+    """tests/GpuTest.py:561-582 (test_uniformGridComputeEqualNumpy), atol 1e-3."""
+    k = golden("ref_kat.npz")
+    compute.prepareLS(k["grid1"], [(0, 0)], k["grid2"], np.array([0, 0, 0]), True)
+    H, b = compute.dispatchLS(k["grid2"])
+    assert np.allclose(H, k["grid_H"], atol=1e-3)
+    assert np.allclose(b, k["grid_b"].T, atol=1e-3)
+    st = O.RingIcp(100)
+    st.prepare_ls(k["grid1"], [(0, 0)], np.zeros(3), debug=True)
+    rH, rb = st.dispatch_ls(k["grid2"])
+    assert np.array_equal(bits(H), bits(rH)) and np.array_equal(bits(b), bits(rb))
+
+
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 4095, 4096, 4097, 123645, 200000])
+def test_hb_sum_matches_tree_bitwise(compute, n):
+    rng = np.random.default_rng(n)
+    tiles = (rng.standard_normal((n, 8, 8)) * rng.choice([1e-3, 1.0, 1e3], (n, 1, 1))).astype(np.float32)
+    out = compute.hbSum(tiles)
+    assert np.array_equal(bits(out), bits(O.hb_tree_sum(tiles)))
+
+
+# ------------------------------------------------------------------------------ device-resident loop (a-7, a-8)
+def _pose_close(t, R, rt, rR):
+    assert np.abs(R - rR).max() < 1e-5
+    assert np.abs(t - rt).max() < 1e-4
+
+
+def test_icp_point_small_matches_oracle(compute):
+    a, b = small_pair()
+    lines = O.get_scan_lines(a, ORIGIN)
+    compute.prepareLS(a, lines, b, ORIGIN)
+    dx, conv, hb, moved = compute.icpRun(b, MODE_POINT, 8, want_points=True, want_hb=True)
+    tr = []
+    rt, rR = O.full_pt2pt(a, b, ORIGIN, iterations=8, trace=tr)
+    assert len(dx) == 8 and not conv
+    for i, (H, bb, d) in enumerate(tr):
+        assert np.array_equal(bits(hb[i][:6, :6]), bits(H)), f"H at iteration {i}"
+        assert np.array_equal(bits(hb[i][:6, 6]), bits(bb)), f"b at iteration {i}"
+        assert np.array_equal(bits(dx[i]), bits(d)), f"dx at iteration {i}"
+    t, R = PointcloudIcpContainer(compute).full_pt2pt(a, b, ORIGIN, iterations=8)
+    _pose_close(t, R, rt, rR)
+
+
+def test_icp_plane_small_matches_oracle(compute):
+    a, b = small_pair()
+    icp = PointcloudIcpContainer(compute)
+    for full_iter in (False, True):
+        tr = []
+        rt, rR = O.full_pt2pl(a, b, ORIGIN, iterations=12, full_iter=full_iter, trace=tr)
+        icp.preparePointToPlane(a, ORIGIN, b)
+        dx, conv, hb, _ = compute.icpRun(b, MODE_PLANE, 12, full_iter=full_iter, want_hb=True)
+        assert len(dx) == len(tr)
+        for i, (H, bb, d) in enumerate(tr):
+            assert np.array_equal(bits(hb[i][:6, :6]), bits(H)), f"H at iteration {i}"
+            assert np.array_equal(bits(dx[i]), bits(d)), f"dx at iteration {i}"
+        t, R = icp.full_pt2pl(a, b, ORIGIN, iterations=12, full_iter=full_iter)
+        _pose_close(t, R, rt, rR)
+
+
+def test_icp_kitti_matches_golden(compute):
+    a, b = kitti_pair()
+    g = golden("oracle_kitti.npz")
+    icp = PointcloudIcpContainer(compute)
+    t, R = icp.full_pt2pt(a, b, ORIGIN, iterations=20)
+    _pose_close(t, R, g["p2p_t"], g["p2p_R"])
+    icp.preparePointToPoint(a, ORIGIN, b)
+    dx, _, hb, _ = compute.icpRun(b, MODE_POINT, 20, want_hb=True)
+    assert np.array_equal(bits(hb[:, :6, :7]), bits(g["p2p_hb"]))
+    assert np.array_equal(bits(dx), bits(g["p2p_dx"]))
+    t, R = icp.full_pt2pl(a, b, ORIGIN, iterations=10)
+    _pose_close(t, R, g["p2l_t"], g["p2l_R"])
+    icp.preparePointToPlane(a, ORIGIN, b)
+    dx, _, hb, _ = compute.icpRun(b, MODE_PLANE, 10, want_hb=True)
+    assert np.array_equal(bits(hb[:, :6, :7]), bits(g["p2l_hb"]))
+    assert np.array_equal(bits(dx), bits(g["p2l_dx"]))
+
+
+def test_stepwise_protocol_equals_device_loop(compute):
+    """dispatchPointToPlane per iteration on the host (the reference's loop) and
+    the device-resident loop land on the same pose."""
+    a, b = small_pair()
+    icp = PointcloudIcpContainer(compute)
+    icp.preparePointToPlane(a, ORIGIN, b)
+    grid = icp.getUniformGrid(10)
+    cur = b.copy()
+    for _ in range(6):
+        t, R, delta = icp.dispatchPointToPlane(cur)
+        cur = icp.apply_iteration_of_ls(cur, t, R)
+        grid = icp.applyIcpStep(grid, R, t)
+    R1, t1 = icp.uniform_optimal_icp(grid, icp.getUniformGrid(10))
+    t2, R2 = icp.full_pt2pl(a, b, ORIGIN, iterations=6, full_iter=True)
+    _pose_close(t1, R1, t2, R2)
+
+
+# ------------------------------------------------------------------------------ errors
+def test_error_paths(compute):
+    from pointcloudprocessing_amd import PcpError
+    a, b = small_pair()
+    with pytest.raises(PcpError):
+        compute.prepareNNS(a, [(0, len(a) + 5)], b, ORIGIN)        # ring past the cloud
+    with pytest.raises(PcpError):
+        compute.prepareLS(a, [(i, i) for i in range(101)], b, ORIGIN)   # > maxScans
+    lines = O.get_scan_lines(a, ORIGIN)
+    compute.prepareLS(a, lines, b, ORIGIN)
+    with pytest.raises(PcpError):
+        compute.dispatchPointPlane(b)                              # no normals for this target
+    with pytest.raises(PcpError):
+        compute.dispatchLS(np.zeros((0, 3)))
