@@ -26,6 +26,8 @@ using namespace pcp;
 
 namespace {
 
+#define PCP_BLOCK 64   // threads per block of the search kernels
+
 struct IcpState {
     double R[9];
     double t[3];
@@ -56,8 +58,8 @@ __device__ __forceinline__ void load_scan(int2* s_scan, const int2* __restrict__
     __syncthreads();
 }
 
-// NearestNeighbourScan.glsl:1-35
-__global__ void __launch_bounds__(256)
+// NearestNeighbourScan.glsl:1-35.  One wave per block = one shader workgroup.
+__global__ void __launch_bounds__(PCP_BLOCK)
 k_nn(const float4* __restrict__ a, const float4* __restrict__ ua, const int2* __restrict__ scan,
      int n_a, int Z, float4 o, const float4* __restrict__ b, int n_b,
      float* __restrict__ hint, uint32_t* __restrict__ idx, float* __restrict__ dist) {
@@ -86,7 +88,7 @@ __device__ __forceinline__ int closest_distinct(const Target& T, const float4 q,
     return best;
 }
 
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(PCP_BLOCK)
 k_normals(const float4* __restrict__ a, const float4* __restrict__ ua, const int2* __restrict__ scan,
           int n_a, int Z, float4 o, float4* __restrict__ normals) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -141,7 +143,7 @@ k_normals(const float4* __restrict__ a, const float4* __restrict__ ua, const int
 //           left pending by the previous iteration is applied first
 //           (apply_iteration_of_ls, PointcloudIcpContainer.py:172-174).
 template <int MODE, bool F64SRC>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(PCP_BLOCK)
 k_ls(const float4* __restrict__ a, const float4* __restrict__ ua, const int2* __restrict__ scan,
      int n_a, int Z, float4 o, const float4* __restrict__ normals,
      const float4* __restrict__ b32, double* __restrict__ b64, IcpState* __restrict__ st,
@@ -206,54 +208,79 @@ k_ls(const float4* __restrict__ a, const float4* __restrict__ ua, const int2* __
     if ((wave << 6) < n_b) {               // wave-uniform
 #pragma unroll
         for (int k = 0; k < PCP_NVAL; ++k) v[k] = wave_tree_sum(v[k]);
-        if (lane == 0) {
-            float* p = partials + (size_t)wave * PCP_PSTRIDE;
+        float mine = 0.0f;       // lane k takes value k from lane 0: one 128-byte store per wave
 #pragma unroll
-            for (int k = 0; k < PCP_NVAL; ++k) p[k] = v[k];
+        for (int k = 0; k < PCP_NVAL; ++k) {
+            const float vk = __shfl(v[k], 0, 64);
+            mine = (lane == k) ? vk : mine;
         }
+        if (lane < PCP_PSTRIDE) partials[(size_t)wave * PCP_PSTRIDE + lane] = mine;
     }
 }
 
 // 6x6 solve in float64: Gaussian elimination with partial pivoting, the
-// arithmetic order of the host checker's solve6.  Returns false when singular.
-__device__ bool solve6(const float* __restrict__ hb /* 8x8 */, double* x) {
+// arithmetic order of the host checker's solve6.  Every index is a compile-time
+// constant after unrolling (the row exchange is a predicated select), so the
+// system lives in registers.  Returns false when singular.
+__device__ __forceinline__ bool solve6(const double (&H)[6][6], const double (&rhs)[6], double (&x)[6]) {
     double A[6][6];
+#pragma unroll
     for (int r = 0; r < 6; ++r) {
-        for (int c = 0; c < 6; ++c) A[r][c] = (double)hb[r * 8 + c];
-        x[r] = -(double)hb[r * 8 + 6];
+#pragma unroll
+        for (int c = 0; c < 6; ++c) A[r][c] = H[r][c];
+        x[r] = rhs[r];
     }
+    bool ok = true;
+#pragma unroll
     for (int k = 0; k < 6; ++k) {
         int p = k;
+        double piv = A[k][k];
+#pragma unroll
         for (int r = k + 1; r < 6; ++r)
-            if (fabs(A[r][k]) > fabs(A[p][k])) p = r;
-        if (A[p][k] == 0.0 || A[p][k] != A[p][k]) return false;
-        if (p != k) {
-            for (int c = 0; c < 6; ++c) { const double tmp = A[k][c]; A[k][c] = A[p][c]; A[p][c] = tmp; }
-            const double tmp = x[k]; x[k] = x[p]; x[p] = tmp;
+            if (fabs(A[r][k]) > fabs(piv)) { piv = A[r][k]; p = r; }
+        if (piv == 0.0 || piv != piv) ok = false;
+#pragma unroll
+        for (int r = k + 1; r < 6; ++r) {
+            const bool sw = (p == r);
+#pragma unroll
+            for (int c = 0; c < 6; ++c) {
+                const double top = A[k][c], bot = A[r][c];
+                A[k][c] = sw ? bot : top;
+                A[r][c] = sw ? top : bot;
+            }
+            const double top = x[k], bot = x[r];
+            x[k] = sw ? bot : top;
+            x[r] = sw ? top : bot;
         }
+#pragma unroll
         for (int r = k + 1; r < 6; ++r) {
             const double m = A[r][k] / A[k][k];
+#pragma unroll
             for (int c = k + 1; c < 6; ++c) A[r][c] = A[r][c] - m * A[k][c];
             x[r] = x[r] - m * x[k];
         }
     }
+#pragma unroll
     for (int k = 5; k >= 0; --k) {
-        double s = x[k];
-        for (int c = k + 1; c < 6; ++c) s = s - A[k][c] * x[c];
-        x[k] = s / A[k][k];
+        double sum = x[k];
+#pragma unroll
+        for (int c = k + 1; c < 6; ++c) sum = sum - A[k][c] * x[c];
+        x[k] = sum / A[k][k];
     }
-    return true;
+    return ok;
 }
 
-__device__ void mm3(const double* A, const double* B, double* C) {
+__device__ __forceinline__ void mm3(const double* A, const double* B, double* C) {
+#pragma unroll
     for (int i = 0; i < 3; ++i)
+#pragma unroll
         for (int j = 0; j < 3; ++j)
             C[i * 3 + j] = (A[i * 3 + 0] * B[0 * 3 + j] + A[i * 3 + 1] * B[1 * 3 + j]) + A[i * 3 + 2] * B[2 * 3 + j];
 }
 
 // PointcloudAlignment.rotation (PointcloudAlignment.py:229-261): Rx @ Ry @ Rz with
 // float32 trig values held in float64 matrices.
-__device__ void rotation_xyz(float xr, float yr, float zr, double* R) {
+__device__ __forceinline__ void rotation_xyz(float xr, float yr, float zr, double* R) {
     const double cx = (double)(float)cos((double)xr), sx = (double)(float)sin((double)xr);
     const double cy = (double)(float)cos((double)yr), sy = (double)(float)sin((double)yr);
     const double cz = (double)(float)cos((double)zr), sz = (double)(float)sin((double)zr);
@@ -281,19 +308,27 @@ k_finish(const float* __restrict__ partials, int n1, float* __restrict__ lvl0, f
     float* out = lvl0;
     float* other = lvl1;
     int n = n1;
+    // Lane l keeps element (l & 31) of the records with parity (l >> 5): one load
+    // instruction covers two adjacent 128-byte records, the tree steps s = 32..2
+    // pair records of equal parity (register adds), the last step s = 1 pairs
+    // record 0 with record 1 across the two half-waves.
+    const int e = lane & 31, par = lane >> 5;
     while (n > 1) {
         const int groups = (n + 63) >> 6;
         for (int g = wave; g < groups; g += nwaves) {
-            const int src = g * 64 + lane;
-            float v[PCP_NVAL];
+            float v[32];
 #pragma unroll
-            for (int k = 0; k < PCP_NVAL; ++k) v[k] = (src < n) ? in[(size_t)src * PCP_PSTRIDE + k] : 0.0f;
-#pragma unroll
-            for (int k = 0; k < PCP_NVAL; ++k) v[k] = wave_tree_sum(v[k]);
-            if (lane == 0) {
-#pragma unroll
-                for (int k = 0; k < PCP_NVAL; ++k) out[(size_t)g * PCP_PSTRIDE + k] = v[k];
+            for (int j = 0; j < 32; ++j) {
+                const int rec = g * 64 + 2 * j + par;
+                v[j] = (rec < n) ? in[(size_t)rec * PCP_PSTRIDE + e] : 0.0f;
             }
+#pragma unroll
+            for (int s = 16; s > 0; s >>= 1) {
+#pragma unroll
+                for (int j = 0; j < s; ++j) v[j] = v[j] + v[j + s];
+            }
+            const float sum = v[0] + __shfl_down(v[0], 32, 64);
+            if (par == 0) out[(size_t)g * PCP_PSTRIDE + e] = sum;
         }
         __threadfence_block();
         __syncthreads();
@@ -303,17 +338,28 @@ k_finish(const float* __restrict__ partials, int n1, float* __restrict__ lvl0, f
     }
     if (threadIdx.x != 0) return;
     const int it = solve ? st->iter : 0;
+    float v[PCP_NVAL];
+#pragma unroll
+    for (int k = 0; k < PCP_NVAL; ++k) v[k] = in[k];
     float* hb = hb_out + (size_t)it * 64;
+#pragma unroll
     for (int r = 0; r < 8; ++r)
+#pragma unroll
         for (int c = 0; c < 8; ++c) {
             float val = 0.0f;
-            if (r < 6 && c < 6) val = in[r <= c ? tri(r, c) : tri(c, r)];
-            else if (r < 6 && c == 6) val = in[21 + r];
+            if (r < 6 && c < 6) val = v[r <= c ? tri(r, c) : tri(c, r)];
+            else if (r < 6 && c == 6) val = v[21 + r];
             hb[r * 8 + c] = val;
         }
     if (!solve) return;
-    double x[6];
-    if (!solve6(hb, x)) {
+    double H[6][6], rhs[6], x[6];
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+#pragma unroll
+        for (int c = 0; c < 6; ++c) H[r][c] = (double)v[r <= c ? tri(r, c) : tri(c, r)];
+        rhs[r] = -(double)v[21 + r];
+    }
+    if (!solve6(H, rhs, x)) {
         st->singular = 1;
         st->done = 1;
         st->pending = 0;
@@ -321,10 +367,12 @@ k_finish(const float* __restrict__ partials, int n1, float* __restrict__ lvl0, f
         return;
     }
     float dx[6];
+#pragma unroll
     for (int k = 0; k < 6; ++k) { dx[k] = (float)x[k]; dx_out[(size_t)it * 6 + k] = dx[k]; }
     st->iter = it + 1;
     if (mode == PCP_MODE_PLANE && !full_iter) {
         float s = 0.0f;                       // np.mean(np.abs(delta_x)), float32
+#pragma unroll
         for (int k = 0; k < 6; ++k) s = s + fabsf(dx[k]);
         if (s / 6.0f < tol) {
             st->converged = 1;
@@ -434,7 +482,7 @@ int upload_b32(pcp_ctx* c, const float* b_xyzw, int n_b) {
 
 int launch_ls(pcp_ctx* c, int mode, bool f64src, int debug, float* tiles) {
     const int n_b = c->n_b;
-    const dim3 grid(cdiv(n_b, 256)), block(256);
+    const dim3 grid(cdiv(n_b, PCP_BLOCK)), block(PCP_BLOCK);
     const size_t sm = scan_smem(c);
     if (mode == PCP_MODE_PLANE && !c->have_normals) return pcp_fail("plane mode needs pcp_normals after pcp_set_target");
     if (debug && n_b > c->n_a) return pcp_fail("identity correspondences need n_b <= n_a");
@@ -585,7 +633,7 @@ int pcp_prepare_resident(pcp_ctx* c, int with_normals) {
     if (int e = pcp_reset_hints(c)) return e;
     if (with_normals) {
         if (c->n_scans < 2) return pcp_fail("normals need at least 2 scan lines");
-        hipLaunchKernelGGL(k_normals, dim3(cdiv(c->n_a, 256)), dim3(256), scan_smem(c), c->stream, c->a, c->ua,
+        hipLaunchKernelGGL(k_normals, dim3(cdiv(c->n_a, PCP_BLOCK)), dim3(PCP_BLOCK), scan_smem(c), c->stream, c->a, c->ua,
                            c->scan, c->n_a, c->n_scans, c->origin, c->normals);
         PCP_CHECK(hipGetLastError());
         c->have_normals = true;
@@ -624,7 +672,7 @@ int pcp_normals(pcp_ctx* c, float* out_normals) {
     if (int e = use(c)) return e;
     if (!c->have_target) return pcp_fail("no target: call pcp_set_target first");
     if (c->n_scans < 2) return pcp_fail("normals need at least 2 scan lines");
-    hipLaunchKernelGGL(k_normals, dim3(cdiv(c->n_a, 256)), dim3(256), scan_smem(c), c->stream, c->a, c->ua, c->scan,
+    hipLaunchKernelGGL(k_normals, dim3(cdiv(c->n_a, PCP_BLOCK)), dim3(PCP_BLOCK), scan_smem(c), c->stream, c->a, c->ua, c->scan,
                        c->n_a, c->n_scans, c->origin, c->normals);
     PCP_CHECK(hipGetLastError());
     c->have_normals = true;
@@ -639,7 +687,7 @@ int pcp_nn(pcp_ctx* c, const float* b_xyzw, int n_b, uint32_t* idx, float* dist2
     if (int e = use(c)) return e;
     if (!idx || !dist2) return pcp_fail("null output");
     if (int e = upload_b32(c, b_xyzw, n_b)) return e;
-    hipLaunchKernelGGL(k_nn, dim3(cdiv(n_b, 256)), dim3(256), scan_smem(c), c->stream, c->a, c->ua, c->scan, c->n_a,
+    hipLaunchKernelGGL(k_nn, dim3(cdiv(n_b, PCP_BLOCK)), dim3(PCP_BLOCK), scan_smem(c), c->stream, c->a, c->ua, c->scan, c->n_a,
                        c->n_scans, c->origin, c->b32, n_b, c->hint, c->nn_idx, c->nn_dist);
     PCP_CHECK(hipGetLastError());
     PCP_CHECK(hipMemcpyAsync(idx, c->nn_idx, (size_t)n_b * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
