@@ -109,12 +109,22 @@ int pcp_icp_run(pcp_ctx* ctx, const double* b_xyz, int n_b, int mode, int max_it
 /* The same loop split for callers that keep data in device memory: upload
  * once, launch without host synchronisation, fetch the small result later. */
 int pcp_upload_source(pcp_ctx* ctx, const double* b_xyz, int n_b);
+/* Same from a buffer already in device memory (device-to-device copy on the
+ * context's stream). */
+int pcp_upload_source_dev(pcp_ctx* ctx, const double* b_xyz_dev, int n_b);
 int pcp_icp_launch(pcp_ctx* ctx, int mode, int max_iter, float tol, int full_iter);
 int pcp_icp_fetch(pcp_ctx* ctx, float* dx_trace, float* hb_trace, int* iters,
                   int* converged, double* b_out);
 /* Recompute unit vectors (+ normals when with_normals) and reset hints for the
  * target already resident in ctx: the kernel half of prepare*, no upload. */
 int pcp_prepare_resident(pcp_ctx* ctx, int with_normals);
+
+/* Per-kernel timing of the loop: while enabled, pcp_icp_launch records a HIP
+ * event before and after every fused NN + least-squares launch on the
+ * context's stream; pcp_profile_read waits for the stream and returns the
+ * summed duration of the launches that did work and their count. */
+int pcp_profile_enable(pcp_ctx* ctx, int on);
+int pcp_profile_read(pcp_ctx* ctx, float* ls_ms, int* launches);
 
 /* Elapsed milliseconds between two points of the context's stream, measured
  * with HIP events recorded on that stream. */

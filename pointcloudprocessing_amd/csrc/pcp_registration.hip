@@ -3,7 +3,8 @@
 // Data layout in device memory, per context:
 //   a, ua, normals  float4[n_a]   target cloud, its unit-sphere projection, ring normals
 //   b32             float4[n_b]   source cloud as the kernels see it (stepwise calls)
-//   b64             double[3*n_b] source cloud of the device-resident loop (moved in place)
+//   b_in, b64       double[3*n_b] source cloud of the device-resident loop as uploaded, and
+//                                 its working copy (written by iteration 0, then moved in place)
 //   hint            float[n_b]    corr[:,3] of the reference: ring of the last match, -1 = none
 //   partials        float[ceil(n_b/64)][32]  level-1 sums of 64 consecutive points
 //                                 (27 used: 21 upper-triangle JtJ + 6 Jte)
@@ -146,8 +147,8 @@ template <int MODE, bool F64SRC>
 __global__ void __launch_bounds__(PCP_BLOCK)
 k_ls(const float4* __restrict__ a, const float4* __restrict__ ua, const int2* __restrict__ scan,
      int n_a, int Z, float4 o, const float4* __restrict__ normals,
-     const float4* __restrict__ b32, double* __restrict__ b64, IcpState* __restrict__ st,
-     int n_b, int debug, float* __restrict__ hint, float* __restrict__ partials,
+     const float4* __restrict__ b32, const double* __restrict__ b_in, double* __restrict__ b64,
+     IcpState* __restrict__ st, int n_b, int debug, float* __restrict__ hint, float* __restrict__ partials,
      float* __restrict__ tiles) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int2* s_scan = reinterpret_cast<int2*>(smem);
@@ -163,12 +164,16 @@ k_ls(const float4* __restrict__ a, const float4* __restrict__ ua, const int2* __
     if (in) {
         float4 q;
         if (F64SRC) {
-            double px = b64[3 * (size_t)i + 0], py = b64[3 * (size_t)i + 1], pz = b64[3 * (size_t)i + 2];
+            const bool first = st->iter == 0;       // iteration 0 reads the cloud as uploaded
+            const double* rd = first ? b_in : b64;
+            double px = rd[3 * (size_t)i + 0], py = rd[3 * (size_t)i + 1], pz = rd[3 * (size_t)i + 2];
             if (st->pending) {
                 const double nx = ((st->R[0] * px + st->R[1] * py) + st->R[2] * pz) - st->t[0];
                 const double ny = ((st->R[3] * px + st->R[4] * py) + st->R[5] * pz) - st->t[1];
                 const double nz = ((st->R[6] * px + st->R[7] * py) + st->R[8] * pz) - st->t[2];
                 px = nx; py = ny; pz = nz;
+            }
+            if (st->pending || first) {
                 b64[3 * (size_t)i + 0] = px; b64[3 * (size_t)i + 1] = py; b64[3 * (size_t)i + 2] = pz;
             }
             q = make_float4((float)px, (float)py, (float)pz, 0.0f);
@@ -437,7 +442,7 @@ struct pcp_ctx {
     int device = 0, max_points = 0, max_scans = 0;
     hipStream_t own_stream = nullptr, stream = nullptr;
     float4 *a = nullptr, *ua = nullptr, *normals = nullptr, *b32 = nullptr;
-    double* b64 = nullptr;
+    double *b_in = nullptr, *b64 = nullptr;
     float *hint = nullptr, *nn_dist = nullptr;
     uint32_t* nn_idx = nullptr;
     int2* scan = nullptr;
@@ -450,6 +455,9 @@ struct pcp_ctx {
     bool have_target = false, have_normals = false;
     int run_mode = 0, run_max_iter = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool profile = false;                 // bracket every LS launch of the loop with events
+    std::vector<hipEvent_t> prof_events;  // pairs (before, after), created on demand
+    int prof_used = 0;
     static const int max_iter_cap = 1024;
 };
 
@@ -486,7 +494,7 @@ int launch_ls(pcp_ctx* c, int mode, bool f64src, int debug, float* tiles) {
     const size_t sm = scan_smem(c);
     if (mode == PCP_MODE_PLANE && !c->have_normals) return pcp_fail("plane mode needs pcp_normals after pcp_set_target");
     if (debug && n_b > c->n_a) return pcp_fail("identity correspondences need n_b <= n_a");
-#define PCP_LS_ARGS c->a, c->ua, c->scan, c->n_a, c->n_scans, c->origin, c->normals, c->b32, c->b64, c->state, \
+#define PCP_LS_ARGS c->a, c->ua, c->scan, c->n_a, c->n_scans, c->origin, c->normals, c->b32, c->b_in, c->b64, c->state, \
                     n_b, debug, c->hint, c->partials, tiles
     if (mode == PCP_MODE_POINT) {
         if (f64src) hipLaunchKernelGGL((k_ls<PCP_MODE_POINT, true>), grid, block, sm, c->stream, PCP_LS_ARGS);
@@ -567,6 +575,7 @@ int pcp_create(int device, int max_points, int max_scans, pcp_ctx** out) {
     A((void**)&c->ua, n * sizeof(float4));
     A((void**)&c->normals, n * sizeof(float4));
     A((void**)&c->b32, n * sizeof(float4));
+    A((void**)&c->b_in, n * 3 * sizeof(double));
     A((void**)&c->b64, n * 3 * sizeof(double));
     A((void**)&c->hint, n * sizeof(float));
     A((void**)&c->nn_dist, n * sizeof(float));
@@ -595,10 +604,11 @@ int pcp_destroy(pcp_ctx* c) {
     if (!c) return 0;
     (void)hipSetDevice(c->device);
     if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
-    void* bufs[] = {c->a, c->ua, c->normals, c->b32, c->b64, c->hint, c->nn_dist, c->nn_idx, c->scan,
+    void* bufs[] = {c->a, c->ua, c->normals, c->b32, c->b_in, c->b64, c->hint, c->nn_dist, c->nn_idx, c->scan,
                     c->partials, c->lvl0, c->lvl1, c->hb_trace, c->dx_trace, c->state, c->tiles, c->tiles2};
     for (void* p : bufs)
         if (p) (void)hipFree(p);
+    for (hipEvent_t ev : c->prof_events) (void)hipEventDestroy(ev);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -753,7 +763,16 @@ int pcp_upload_source(pcp_ctx* c, const double* b_xyz, int n_b) {
     if (!b_xyz) return pcp_fail("null source points");
     if (n_b < 1 || n_b > c->max_points) return pcp_fail("n_b = %d outside [1, %d]", n_b, c->max_points);
     c->n_b = n_b;
-    PCP_CHECK(hipMemcpyAsync(c->b64, b_xyz, (size_t)n_b * 3 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    PCP_CHECK(hipMemcpyAsync(c->b_in, b_xyz, (size_t)n_b * 3 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    return 0;
+}
+
+int pcp_upload_source_dev(pcp_ctx* c, const double* b_xyz_dev, int n_b) {
+    if (int e = use(c)) return e;
+    if (!b_xyz_dev) return pcp_fail("null source points");
+    if (n_b < 1 || n_b > c->max_points) return pcp_fail("n_b = %d outside [1, %d]", n_b, c->max_points);
+    c->n_b = n_b;
+    PCP_CHECK(hipMemcpyAsync(c->b_in, b_xyz_dev, (size_t)n_b * 3 * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
     return 0;
 }
 
@@ -767,8 +786,23 @@ int pcp_icp_launch(pcp_ctx* c, int mode, int max_iter, float tol, int full_iter)
     PCP_CHECK(hipMemsetAsync(c->state, 0, sizeof(IcpState), c->stream));
     c->run_mode = mode;
     c->run_max_iter = max_iter;
+    if (max_iter == 0)
+        PCP_CHECK(hipMemcpyAsync(c->b64, c->b_in, (size_t)c->n_b * 3 * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    c->prof_used = 0;
     for (int it = 0; it < max_iter; ++it) {
+        if (c->profile) {
+            while ((int)c->prof_events.size() < 2 * (it + 1)) {
+                hipEvent_t ev;
+                PCP_CHECK(hipEventCreate(&ev));
+                c->prof_events.push_back(ev);
+            }
+            PCP_CHECK(hipEventRecord(c->prof_events[2 * it], c->stream));
+        }
         if (int e = launch_ls(c, mode, true, 0, nullptr)) return e;
+        if (c->profile) {
+            PCP_CHECK(hipEventRecord(c->prof_events[2 * it + 1], c->stream));
+            c->prof_used = it + 1;
+        }
         if (int e = launch_finish(c, 1, mode, max_iter, tol, full_iter)) return e;
     }
     hipLaunchKernelGGL(k_apply_pending, dim3(cdiv(c->n_b, 256)), dim3(256), 0, c->stream, c->b64, c->n_b, c->state);
@@ -803,6 +837,31 @@ int pcp_icp_run(pcp_ctx* c, const double* b_xyz, int n_b, int mode, int max_iter
     if (int e = pcp_reset_hints(c)) return e;
     if (int e = pcp_icp_launch(c, mode, max_iter, tol, full_iter)) return e;
     return pcp_icp_fetch(c, dx_trace, hb_trace, iters, converged, b_out);
+}
+
+int pcp_profile_enable(pcp_ctx* c, int on) {
+    if (!c) return pcp_fail("null context");
+    c->profile = on != 0;
+    return 0;
+}
+
+int pcp_profile_read(pcp_ctx* c, float* ls_ms, int* launches) {
+    if (int e = use(c)) return e;
+    if (!ls_ms || !launches) return pcp_fail("null output");
+    PCP_CHECK(hipStreamSynchronize(c->stream));
+    IcpState st;
+    PCP_CHECK(hipMemcpy(&st, c->state, sizeof(IcpState), hipMemcpyDeviceToHost));
+    // launches past the loop's end return at once (done flag); only the dispatches that ran count
+    const int n = st.iter < c->prof_used ? st.iter : c->prof_used;
+    float total = 0.f;
+    for (int i = 0; i < n; ++i) {
+        float ms = 0.f;
+        PCP_CHECK(hipEventElapsedTime(&ms, c->prof_events[2 * i], c->prof_events[2 * i + 1]));
+        total += ms;
+    }
+    *ls_ms = total;
+    *launches = n;
+    return 0;
 }
 
 int pcp_timer_start(pcp_ctx* c) {
