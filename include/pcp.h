@@ -119,6 +119,39 @@ int pcp_icp_fetch(pcp_ctx* ctx, float* dx_trace, float* hb_trace, int* iters,
  * target already resident in ctx: the kernel half of prepare*, no upload. */
 int pcp_prepare_resident(pcp_ctx* ctx, int with_normals);
 
+/* ---- voxel map (Voxelizer.py's device half) ------------------------------
+ * Layouts are the reference's: voxel_index int32 rows of 4 (vx, vy, vz,
+ * data_row) sorted lexicographically; voxel_data int32 rows of max_points
+ * ([0] = count, [1..] = global point ids); voxel_stat float32 rows of 4
+ * (prob, count + max prob, stage status, staged) indexed by data_row. */
+
+/* bufferVoxelIndex (ComputeShader.py:837-840). */
+int pcp_voxel_index_upload(pcp_ctx* ctx, const int32_t* voxel_index, int rows);
+/* fullBufferVoxelData (:842-845): replaces the resident voxel data. */
+int pcp_voxel_data_upload(pcp_ctx* ctx, const int32_t* voxel_data, int rows, int max_points);
+/* The sub-range branch of prepareDispatchVoxelizer (:863-878): rows
+ * [first_row, first_row + n_rows) of the resident voxel data. */
+int pcp_voxel_data_upload_rows(pcp_ctx* ctx, const int32_t* rows_data, int first_row,
+                               int n_rows, int max_points);
+/* getFullVoxelData (:946-954): the first `rows` rows back to the host. */
+int pcp_voxel_data_read(pcp_ctx* ctx, int rows, int max_points, int32_t* out);
+/* The dispatch half of prepareDispatchVoxelizer (:881-944), kernel
+ * VoxelShader.glsl: every point is appended to its voxel's row or, when its
+ * voxel is not in the table, to the unknown list.  unknown receives
+ * [count, ids..., 0 padding] (unknown_len >= n + 1 ints, as the caller pads
+ * it); debug (n x 4 floats: vx, vy, vz, table position) may be NULL. */
+int pcp_voxelize(pcp_ctx* ctx, const float* pts_xyzw, int n, float voxel_size, int stored,
+                 int begin_index, int max_points, int32_t* unknown, int unknown_len,
+                 float* debug);
+/* prepareDispatchVoxelStager (:761-835), kernel VoxelStage.glsl, on the table
+ * and voxel data already resident.  voxel_stat (stat_rows x 4) is uploaded,
+ * updated and read back in place; counter16 receives the counter buffer
+ * ([0] = rows staged by this call); stage_out (may be NULL) receives the
+ * first counter16[0] staged rows of max_points ints. */
+int pcp_voxel_stage(pcp_ctx* ctx, float* voxel_stat, int stat_rows, int stored, int max_points,
+                    int filter_outliers, int stage_everything, int max_staging,
+                    int32_t* counter16, int32_t* stage_out);
+
 /* Per-kernel timing of the loop: while enabled, pcp_icp_launch records a HIP
  * event before and after every fused NN + least-squares launch on the
  * context's stream; pcp_profile_read waits for the stream and returns the

@@ -7,6 +7,7 @@ Needs /root/reference (read-only).  Three kinds of vectors:
   ref_kat.npz      outputs of the reference's OWN importable CPU functions
                    (PointcloudIcpContainer, PointcloudAlignment), the known
                    answers that pin the restatement in oracle/np_oracle.py
+  ref_voxel.npz    the reference's own Voxelizer (CPU path) on the two KITTI frames
   oracle_kitti.npz outputs of oracle/np_oracle.py on the KITTI pair (full-size
                    parity targets for the HIP kernels, so GPU tests need not
                    rerun the slow NumPy search)
@@ -106,6 +107,46 @@ def ref_kat(raw):
     return frames
 
 
+def ref_voxel(frames):
+    """The reference's own Voxelizer, CPU path only (cpuGpuDebug_dispatchVoxels +
+    storeUnknownPoints, Voxelizer.py:308-344, :170-306), on KITTI frames 0 and 1 at 0.5 m.
+    Renderer / VoxelManager are GL-only imports of that module; empty stand-in
+    modules satisfy the import (nothing of them is called with renderer=None)."""
+    import types
+    for name in ("Renderer", "VoxelManager"):
+        m = types.ModuleType(name)
+        setattr(m, name, type(name, (), {"__init__": lambda self, *a, **k: None}))
+        sys.modules[name] = m
+    from Voxelizer import Voxelizer
+    class HostOnly:
+        """On the CPU path the host arrays already hold every row, so the read-back
+        the reference asks for when it grows (Voxelizer.py:241-244) has nothing to add."""
+        def getFullVoxelData(self, prev_stored_voxels, max_points, voxel_data):
+            pass
+    v = Voxelizer(HostOnly(), None)
+    v.init(0.5)
+    out = {"voxel_size": 0.5}
+    for k, pc in enumerate(frames):
+        v.handleAddingPoints(pc.astype(np.float32))
+        begin = v.last_added_point - len(pc)
+        unknown, v.voxel_index, v.voxel_data, coords, entries = v.cpuGpuDebug_dispatchVoxels(
+            np_points=pc, voxel_index=v.voxel_index, voxel_data=v.voxel_data, voxel_size=v.voxel_size,
+            stored_voxel_num=v.stored_voxels, begin_index=begin)
+        out[f"unknown_count{k}"] = int(unknown[0])
+        out[f"unknown_sorted_sha{k}"] = sha(np.sort(unknown[1:1 + unknown[0]]))
+        out[f"coords_sha{k}"] = sha(coords.astype(np.int32))
+        out[f"entries_sha{k}"] = sha(entries.astype(np.int32))
+        v.storeUnknownPoints(unknown)
+        out[f"stored{k}"] = v.stored_voxels
+        out[f"capacity{k}"] = len(v.voxel_index)
+    s = v.stored_voxels
+    out["voxel_index"] = v.voxel_index[:s].copy()
+    out["counts"] = v.voxel_data[:s, 0].copy()
+    rows = [np.sort(v.voxel_data[r, 1:min(v.voxel_data[r, 0] + 1, v.max_points)]) for r in range(s)]
+    out["ids_sha"] = sha(np.concatenate(rows))
+    np.savez_compressed(os.path.join(OUT, "ref_voxel.npz"), **out)
+
+
 def oracle_kitti(frames):
     from oracle import np_oracle as O
     A, B = frames
@@ -142,6 +183,8 @@ if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     raw = kitti_pair()
     frames = ref_kat(raw)
+    if "--no-voxel" not in sys.argv:
+        ref_voxel(frames)
     if "--no-oracle" not in sys.argv:
         oracle_kitti(frames)
     for f in sorted(os.listdir(OUT)):

@@ -50,6 +50,12 @@ SIGNATURES = {
     "pcp_icp_launch": (C.c_int, [_ctx, C.c_int, C.c_int, C.c_float, C.c_int]),
     "pcp_icp_fetch": (C.c_int, [_ctx, _f32p, _f32p, _i32p, _i32p, _f64p]),
     "pcp_prepare_resident": (C.c_int, [_ctx, C.c_int]),
+    "pcp_voxel_index_upload": (C.c_int, [_ctx, _i32p, C.c_int]),
+    "pcp_voxel_data_upload": (C.c_int, [_ctx, _i32p, C.c_int, C.c_int]),
+    "pcp_voxel_data_upload_rows": (C.c_int, [_ctx, _i32p, C.c_int, C.c_int, C.c_int]),
+    "pcp_voxel_data_read": (C.c_int, [_ctx, C.c_int, C.c_int, _i32p]),
+    "pcp_voxelize": (C.c_int, [_ctx, _f32p, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, _i32p, C.c_int, _f32p]),
+    "pcp_voxel_stage": (C.c_int, [_ctx, _f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _i32p, _i32p]),
     "pcp_profile_enable": (C.c_int, [_ctx, C.c_int]),
     "pcp_profile_read": (C.c_int, [_ctx, _f32p, _i32p]),
     "pcp_timer_start": (C.c_int, [_ctx]),
@@ -90,6 +96,10 @@ def f64p(a):
 
 def u32p(a):
     return None if a is None else _ptr(a, C.c_uint32)
+
+
+def i32p(a):
+    return None if a is None else _ptr(a, C.c_int)
 
 
 def as_f32c(a):

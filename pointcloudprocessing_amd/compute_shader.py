@@ -11,7 +11,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import PcpError, check, f32p, f64p, u32p
+from ._lib import PcpError, check, f32p, f64p, i32p, u32p
 
 MODE_POINT = 0
 MODE_PLANE = 1
@@ -192,6 +192,68 @@ class ComputeShader:
                                     f32p(dx), f32p(hb), C.byref(iters), C.byref(conv), f64p(out)))
         k = iters.value
         return dx[:k], bool(conv.value), (hb[:k] if want_hb else None), out
+
+    # ------------------------------------------------------------------ voxel map
+    def bufferVoxelIndex(self, voxel_index):
+        """:837-840"""
+        vi = np.ascontiguousarray(voxel_index, dtype=np.int32)
+        check(self._lib.pcp_voxel_index_upload(self._ctx, i32p(vi), len(vi)))
+
+    def fullBufferVoxelData(self, voxel_data):
+        """:842-845"""
+        vd = np.ascontiguousarray(voxel_data, dtype=np.int32)
+        check(self._lib.pcp_voxel_data_upload(self._ctx, i32p(vd), vd.shape[0], vd.shape[1]))
+
+    def prepareDispatchVoxelizer(self, np_points, voxel_index, voxel_data, voxel_size, stored_voxel_num,
+                                 begin_index, max_points_to_store, realloc_needed, prev_stored_voxels,
+                                 debug=False):
+        """:847-944 -> (unknown int32[pad16(1 + N)], debug (N, 4) float32 | None).
+        unknown[0] is the count, unknown[1:1+count] the global ids of the points
+        whose voxel is not in the table (in no particular order)."""
+        n = len(np_points)
+        unknown_len = 1 + n
+        unknown_len += 16 - unknown_len % 16
+        unknown_points = np.zeros(unknown_len, dtype=np.int32)
+        self.bufferVoxelIndex(voxel_index)
+        if realloc_needed:
+            self.fullBufferVoxelData(voxel_data)
+        else:
+            new_rows = np.ascontiguousarray(voxel_data[prev_stored_voxels:stored_voxel_num], dtype=np.int32)
+            check(self._lib.pcp_voxel_data_upload_rows(self._ctx, i32p(new_rows), int(prev_stored_voxels),
+                                                       len(new_rows), int(max_points_to_store)))
+        pts = self.pad_points(np_points)
+        debug_data = np.zeros((n, 4), dtype=np.float32) if debug else None
+        check(self._lib.pcp_voxelize(self._ctx, f32p(pts), n, float(np.asarray(voxel_size).reshape(-1)[0]),
+                                     int(stored_voxel_num), int(begin_index), int(max_points_to_store),
+                                     i32p(unknown_points), unknown_len, f32p(debug_data)))
+        return unknown_points, debug_data
+
+    def prepareDispatchVoxelStager(self, voxel_index, stored_voxel_num, max_points, voxel_statistics,
+                                   filter_outliers, stage_everything=False, max_staging=1024, debug=False):
+        """:761-835.  voxel_index is not uploaded here (the reference's upload is
+        commented out, :772-775): the table of the last bufferVoxelIndex /
+        prepareDispatchVoxelizer call is used.  voxel_statistics is updated in place."""
+        if self.voxel_stage_out is None or self.voxel_stage_out.shape != (max_staging, max_points):
+            self.voxel_stage_out = np.zeros((max_staging, max_points), dtype=np.int32)
+        if voxel_statistics.dtype != np.float32 or not voxel_statistics.flags.c_contiguous:
+            raise PcpError("voxel_statistics must be a C-contiguous float32 array")
+        counter = np.zeros((1, 16), dtype=np.int32)
+        check(self._lib.pcp_voxel_stage(self._ctx, f32p(voxel_statistics), len(voxel_statistics),
+                                        int(stored_voxel_num), int(max_points), int(bool(filter_outliers)),
+                                        int(bool(stage_everything)), int(max_staging), i32p(counter),
+                                        i32p(self.voxel_stage_out)))
+        staged = int(counter[0][0])
+        if debug:
+            return voxel_statistics, self.voxel_stage_out, counter
+        if staged > 0:
+            return voxel_statistics, self.voxel_stage_out[:staged]
+        return voxel_statistics, []
+
+    def getFullVoxelData(self, prev_stored_voxels, max_points, voxelizer_voxel_data):
+        """:946-954 -- fills voxelizer_voxel_data[:prev_stored_voxels] in place."""
+        tmp = np.empty((int(prev_stored_voxels), int(max_points)), dtype=np.int32)
+        check(self._lib.pcp_voxel_data_read(self._ctx, len(tmp), int(max_points), i32p(tmp)))
+        voxelizer_voxel_data[:prev_stored_voxels] = tmp
 
     # ------------------------------------------------------------------ life cycle
     def synchronize(self):

@@ -1,0 +1,48 @@
+// Context object behind the opaque pcp_ctx handle, shared by the translation
+// units of libpcp.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <vector>
+
+#define PCP_BLOCK 64   // threads per block of the search kernels
+
+struct IcpState {
+    double R[9];
+    double t[3];
+    int pending;    // (R, t) still has to be applied to the source points
+    int iter;       // dispatches executed so far
+    int done;
+    int converged;
+    int singular;
+    int pad[3];
+};
+
+struct pcp_voxel_state;   // device side of the voxel map, pcp_voxel.hip
+void pcp_voxel_state_free(pcp_voxel_state* v);
+
+struct pcp_ctx {
+    int device = 0, max_points = 0, max_scans = 0;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    float4 *a = nullptr, *ua = nullptr, *normals = nullptr, *b32 = nullptr;
+    double *b_in = nullptr, *b64 = nullptr;
+    float *hint = nullptr, *nn_dist = nullptr;
+    uint32_t* nn_idx = nullptr;
+    int2* scan = nullptr;
+    float *partials = nullptr, *lvl0 = nullptr, *lvl1 = nullptr;
+    float *hb_trace = nullptr, *dx_trace = nullptr;   // max_iter_cap x 64 / x 6
+    IcpState* state = nullptr;
+    float *tiles = nullptr, *tiles2 = nullptr;        // lazily allocated
+    float4 origin = {0, 0, 0, 0};
+    int n_a = 0, n_b = 0, n_scans = 0;
+    bool have_target = false, have_normals = false;
+    int run_mode = 0, run_max_iter = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool profile = false;                 // bracket every LS launch of the loop with events
+    std::vector<hipEvent_t> prof_events;  // pairs (before, after), created on demand
+    int prof_used = 0;
+    pcp_voxel_state* vox = nullptr;      // created by the first voxel call
+    static const int max_iter_cap = 1024;
+};
+

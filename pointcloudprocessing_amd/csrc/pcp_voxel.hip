@@ -1,5 +1,366 @@
 // Voxelizer / voxel stager kernels and their C ABI (see include/pcp.h).
+//
+// Device layout (the reference's SSBO bindings 6-8 and 10-12, ComputeShader.py:144-203):
+//   table   int4[M]            (vx, vy, vz, data_row), lexicographically sorted, voxel_index
+//   data    int[M][max_points] [0] = count (may exceed max_points-1), [1..] = global point ids
+//   stat    float4[M]          (prob, count + max prob, stage status, staged), by data_row
+//   stage   int[max_staging][max_points]   staged rows, never cleared between calls
+//   unknown int[1 + n]         [0] = count, then ids of points whose voxel is not in the table
 #include <hip/hip_runtime.h>
+#include <stdint.h>
 
 #include "../../include/pcp.h"
+#include "pcp_ctx.h"
 #include "pcp_host.h"
+
+struct pcp_voxel_state {
+    int4* table = nullptr;   int table_rows = 0;
+    int* data = nullptr;     int data_rows = 0, data_width = 0;
+    float4 *stat = nullptr, *stat_in = nullptr;   int stat_rows = 0;
+    int* stage = nullptr;    int stage_rows = 0, stage_width = 0;
+    int* unknown = nullptr;  int unknown_cap = 0;
+    float4* pts = nullptr;   float4* debug = nullptr;   int pts_cap = 0;
+    int* counter = nullptr;  // 16 ints
+};
+
+void pcp_voxel_state_free(pcp_voxel_state* v) {
+    if (!v) return;
+    void* bufs[] = {v->table, v->data, v->stat, v->stat_in, v->stage, v->unknown, v->pts, v->debug, v->counter};
+    for (void* p : bufs)
+        if (p) (void)hipFree(p);
+    delete v;
+}
+
+namespace {
+
+// binSearch, VoxelShader.glsl:38-62 (identical copy in VoxelStage.glsl:65-89)
+__device__ __forceinline__ int comp(const int4 v, const int axis) { return axis == 0 ? v.x : (axis == 1 ? v.y : v.z); }
+
+__device__ int bin_search(const int4* __restrict__ table, const int axis, const int value, const bool first,
+                          int l, int h) {
+    int occ = -1;
+    while (l <= h) {
+        const int mid = (l + h) / 2;
+        const int v = comp(table[mid], axis);
+        if (v == value) {
+            occ = mid;
+            if (first) h = mid - 1; else l = mid + 1;
+        } else if (v < value) {
+            l = mid + 1;
+        } else {
+            h = mid - 1;
+        }
+    }
+    return occ;
+}
+
+// findVoxelId, VoxelShader.glsl:64-98
+__device__ int find_voxel(const int4* __restrict__ table, const int stored, const int x, const int y, const int z) {
+    if (stored == 0) return -1;
+    const int fx = bin_search(table, 0, x, true, 0, stored - 1);
+    if (fx == -1) return -1;
+    const int lx = bin_search(table, 0, x, false, 0, stored - 1);
+    const int fy = bin_search(table, 1, y, true, fx, lx);
+    if (fy == -1) return -1;
+    const int ly = bin_search(table, 1, y, false, fx, lx);
+    return bin_search(table, 2, z, true, fy, ly);
+}
+
+// VoxelShader.glsl:100-146
+__global__ void __launch_bounds__(256)
+k_voxelize(const float4* __restrict__ pts, int n, const int4* __restrict__ table, int stored,
+           int* __restrict__ data, int data_rows, int max_points, int begin_index, float voxel_size,
+           int* __restrict__ unknown, float4* __restrict__ debug) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 p = pts[i];
+    const int vx = (int)ceilf(p.x / voxel_size);       // getVoxelCoord, :33-36
+    const int vy = (int)ceilf(p.y / voxel_size);
+    const int vz = (int)ceilf(p.z / voxel_size);
+    const int entry = find_voxel(table, stored, vx, vy, vz);
+    if (debug) debug[i] = make_float4((float)vx, (float)vy, (float)vz, (float)entry);
+    if (entry == -1) {
+        const int k = atomicAdd(&unknown[0], 1);
+        unknown[1 + k] = begin_index + i;
+    } else {
+        const int row = table[entry].w;
+        if ((unsigned)row < (unsigned)data_rows) {      // a malformed table must not fault the device
+            const int c = atomicAdd(&data[(size_t)row * max_points], 1);
+            if (c < max_points - 1) data[(size_t)row * max_points + 1 + c] = begin_index + i;
+        }
+    }
+}
+
+// BayesFilter, VoxelStage.glsl:37-39
+__device__ __forceinline__ float bayes(const float p, const float alpha, const float beta) {
+    return (alpha * p) / (alpha * p + beta * (1.0f - p));
+}
+
+// recoverVoxel + groundRule1/2, VoxelStage.glsl:133-197.  Neighbours are read from
+// the statistics as uploaded (stat_in): the shader reads them while other threads
+// write, this is its all-reads-first outcome.
+__device__ bool recover_voxel(const int4* __restrict__ table, const int stored, const float4* __restrict__ stat_in,
+                              const int stat_rows, const int4 vid) {
+    const int sx[6] = {0, 0, 1, -1, 0, 0}, sy[6] = {1, -1, 0, 0, 0, 0}, sz[6] = {0, 0, 0, 0, 1, -1};
+    bool below_found = false;
+    int horizontal = 0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const int e = find_voxel(table, stored, vid.x + sx[k], vid.y + sy[k], vid.z + sz[k]);
+        bool is_static = false;
+        if (e != -1) {
+            const int row = table[e].w;
+            if ((unsigned)row < (unsigned)stat_rows) {
+                const float4 s = stat_in[row];
+                is_static = s.w > 0.5f || s.z > 0.1f;
+            }
+            if (k == 1) below_found = true;
+        }
+        if (k >= 2 && is_static) ++horizontal;
+    }
+    return horizontal >= 3 || (horizontal >= 2 && !below_found);
+}
+
+// VoxelStage.glsl:201-315.  One lane per table entry; the row copy of
+// tryStageVoxel (:41-60) is done by the whole wave for each staging lane in turn.
+__global__ void __launch_bounds__(256)
+k_voxel_stage(const int4* __restrict__ table, int stored, const int* __restrict__ data, int data_rows,
+              int max_points, float4* __restrict__ stat, const float4* __restrict__ stat_in, int stat_rows,
+              int* __restrict__ stage, int max_staging, int stage_everything, int no_filter,
+              int* __restrict__ counter) {
+    const int pos = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    bool live = pos < stored;
+    int idx = 0, cnt = 0, slot = -1;
+    int4 vid = make_int4(0, 0, 0, 0);
+    if (live) {
+        vid = table[pos];
+        idx = vid.w;
+        live = (unsigned)idx < (unsigned)stat_rows && (unsigned)idx < (unsigned)data_rows;
+    }
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (live) {
+        s = stat[idx];
+        live = !(s.w > 0.5f);                              // staged in an earlier run: nothing to do
+    }
+    bool want_stage = false;
+    if (live) {
+        cnt = data[(size_t)idx * max_points];
+        const float status = s.z;                          // stays stale below, as in the shader (:238-264)
+        if (stage_everything) {
+            if (status > 0.1f) s.z = 0.8f;
+            else if (!no_filter && recover_voxel(table, stored, stat_in, stat_rows, vid)) s.z = 0.8f;
+        }
+        if (status > 0.5f) {
+            want_stage = true;
+        } else {
+            const float mpp = s.y;
+            float max_prob = mpp - (float)(int)mpp;
+            const int prev = (int)mpp;
+            const float alpha = 0.55f, beta = 0.45f;
+            const float nw = (cnt == prev) ? bayes(s.x, 1.0f - alpha, 1.0f - beta) : bayes(s.x, alpha, beta);
+            if (nw > max_prob) max_prob = nw;
+            s.x = nw;
+            if (max_prob > 0.999f) max_prob = 0.999f;
+            if (max_prob < 0.001f) max_prob = 0.001f;
+            s.y = (float)cnt + max_prob;
+            if (nw > 0.9f || status > 0.1f || no_filter) {
+                if (status < 0.1f) s.z = 0.2f;
+                if (cnt + 1 >= max_points) s.z = 0.8f;
+            }
+        }
+    }
+    if (want_stage) {                                      // tryStageVoxel's counter protocol
+        slot = atomicAdd(&counter[0], 1);
+        if (slot >= max_staging) {
+            atomicAdd(&counter[0], -1);
+            slot = -1;
+        } else {
+            s.w = 1.0f;
+        }
+    }
+    if (live) stat[idx] = s;
+    unsigned long long todo = __ballot(slot >= 0);
+    while (todo) {
+        const int src = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+        const int r_idx = __shfl(idx, src, 64), r_cnt = __shfl(cnt, src, 64), r_slot = __shfl(slot, src, 64);
+        const int* from = data + (size_t)r_idx * max_points;
+        int* to = stage + (size_t)r_slot * max_points;
+        if (lane == 0) to[0] = r_cnt;
+        const int end = min(r_cnt + 1, max_points);
+        for (int i = 1 + lane; i < end; i += 64) to[i] = from[i];
+    }
+}
+
+int use(pcp_ctx* c) {
+    if (!c) return pcp_fail("null context");
+    PCP_CHECK(hipSetDevice(c->device));
+    if (!c->vox) {
+        c->vox = new pcp_voxel_state();
+        PCP_CHECK(hipMalloc(&c->vox->counter, 16 * sizeof(int)));
+    }
+    return 0;
+}
+
+template <typename T>
+int grow(T** p, int* cap, size_t want_elems, bool zero, hipStream_t stream) {
+    if ((size_t)*cap >= want_elems && *p) return 0;
+    if (*p) PCP_CHECK(hipFree(*p));
+    *p = nullptr;
+    *cap = 0;
+    PCP_CHECK(hipMalloc(p, want_elems * sizeof(T)));
+    if (zero) PCP_CHECK(hipMemsetAsync(*p, 0, want_elems * sizeof(T), stream));
+    *cap = (int)want_elems;
+    return 0;
+}
+
+inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+}  // namespace
+
+extern "C" {
+
+int pcp_voxel_index_upload(pcp_ctx* c, const int32_t* voxel_index, int rows) {
+    if (int e = use(c)) return e;
+    if (!voxel_index || rows < 1) return pcp_fail("empty voxel index");
+    pcp_voxel_state* v = c->vox;
+    if (rows > v->table_rows) {
+        PCP_CHECK(hipStreamSynchronize(c->stream));
+        if (v->table) PCP_CHECK(hipFree(v->table));
+        v->table = nullptr;
+        v->table_rows = 0;
+        PCP_CHECK(hipMalloc(&v->table, (size_t)rows * sizeof(int4)));
+        v->table_rows = rows;
+    }
+    PCP_CHECK(hipMemcpyAsync(v->table, voxel_index, (size_t)rows * sizeof(int4), hipMemcpyHostToDevice, c->stream));
+    PCP_CHECK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int pcp_voxel_data_upload(pcp_ctx* c, const int32_t* voxel_data, int rows, int max_points) {
+    if (int e = use(c)) return e;
+    if (!voxel_data || rows < 1 || max_points < 2) return pcp_fail("empty voxel data");
+    pcp_voxel_state* v = c->vox;
+    if (rows != v->data_rows || max_points != v->data_width) {
+        PCP_CHECK(hipStreamSynchronize(c->stream));
+        if (v->data) PCP_CHECK(hipFree(v->data));
+        v->data = nullptr;
+        v->data_rows = v->data_width = 0;
+        PCP_CHECK(hipMalloc(&v->data, (size_t)rows * max_points * sizeof(int)));
+        v->data_rows = rows;
+        v->data_width = max_points;
+    }
+    PCP_CHECK(hipMemcpyAsync(v->data, voxel_data, (size_t)rows * max_points * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    PCP_CHECK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int pcp_voxel_data_upload_rows(pcp_ctx* c, const int32_t* rows_data, int first_row, int n_rows, int max_points) {
+    if (int e = use(c)) return e;
+    pcp_voxel_state* v = c->vox;
+    if (n_rows == 0) return 0;
+    if (!rows_data || first_row < 0 || n_rows < 0) return pcp_fail("bad row range");
+    if (!v->data || max_points != v->data_width || first_row + n_rows > v->data_rows)
+        return pcp_fail("rows [%d, %d) x %d do not fit the resident voxel data (%d x %d): upload it whole first",
+                        first_row, first_row + n_rows, max_points, v->data_rows, v->data_width);
+    PCP_CHECK(hipMemcpyAsync(v->data + (size_t)first_row * max_points, rows_data,
+                             (size_t)n_rows * max_points * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    PCP_CHECK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int pcp_voxel_data_read(pcp_ctx* c, int rows, int max_points, int32_t* out) {
+    if (int e = use(c)) return e;
+    pcp_voxel_state* v = c->vox;
+    if (rows == 0) return 0;
+    if (!out || rows < 0) return pcp_fail("bad arguments");
+    if (!v->data || max_points != v->data_width || rows > v->data_rows)
+        return pcp_fail("%d x %d rows requested, %d x %d resident", rows, max_points, v->data_rows, v->data_width);
+    PCP_CHECK(hipMemcpyAsync(out, v->data, (size_t)rows * max_points * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    PCP_CHECK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int pcp_voxelize(pcp_ctx* c, const float* pts_xyzw, int n, float voxel_size, int stored, int begin_index,
+                 int max_points, int32_t* unknown, int unknown_len, float* debug) {
+    if (int e = use(c)) return e;
+    pcp_voxel_state* v = c->vox;
+    if (!pts_xyzw || !unknown) return pcp_fail("null argument");
+    if (n < 1) return pcp_fail("no points to voxelize");
+    if (unknown_len < n + 1) return pcp_fail("unknown list of %d ints cannot hold 1 + %d entries", unknown_len, n);
+    if (!(voxel_size > 0.0f)) return pcp_fail("voxel_size must be positive");
+    if (stored < 0 || stored > v->table_rows) return pcp_fail("stored = %d, resident table has %d rows", stored, v->table_rows);
+    if (stored > 0 && (!v->data || max_points != v->data_width))
+        return pcp_fail("voxel data not resident with row width %d", max_points);
+    if (int e = grow(&v->unknown, &v->unknown_cap, (size_t)n + 1, false, c->stream)) return e;
+    if (n > v->pts_cap) {
+        int cap = v->pts_cap, cap2 = v->pts_cap;
+        if (int e = grow(&v->pts, &cap, (size_t)n, false, c->stream)) return e;
+        if (int e = grow(&v->debug, &cap2, (size_t)n, false, c->stream)) return e;
+        v->pts_cap = cap;
+    }
+    PCP_CHECK(hipMemsetAsync(v->unknown, 0, sizeof(int), c->stream));
+    PCP_CHECK(hipMemcpyAsync(v->pts, pts_xyzw, (size_t)n * sizeof(float4), hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_voxelize, dim3(cdiv(n, 256)), dim3(256), 0, c->stream, v->pts, n, v->table, stored, v->data,
+                       v->data_rows, max_points, begin_index, voxel_size, v->unknown, debug ? v->debug : nullptr);
+    PCP_CHECK(hipGetLastError());
+    int count = 0;
+    PCP_CHECK(hipMemcpyAsync(&count, v->unknown, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    PCP_CHECK(hipStreamSynchronize(c->stream));
+    if (count < 0 || count > n) return pcp_fail("corrupt unknown count %d", count);
+    for (int i = 0; i < unknown_len; ++i) unknown[i] = 0;       // the reference uploads a zeroed list (:855, :881-883)
+    PCP_CHECK(hipMemcpyAsync(unknown, v->unknown, (size_t)(1 + count) * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    if (debug) PCP_CHECK(hipMemcpyAsync(debug, v->debug, (size_t)n * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
+    PCP_CHECK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int pcp_voxel_stage(pcp_ctx* c, float* voxel_stat, int stat_rows, int stored, int max_points, int filter_outliers,
+                    int stage_everything, int max_staging, int32_t* counter16, int32_t* stage_out) {
+    if (int e = use(c)) return e;
+    pcp_voxel_state* v = c->vox;
+    if (!voxel_stat || !counter16) return pcp_fail("null argument");
+    if (stat_rows < 1 || max_staging < 1 || max_points < 2) return pcp_fail("bad sizes");
+    if (stored < 0 || stored > v->table_rows) return pcp_fail("stored = %d, resident table has %d rows", stored, v->table_rows);
+    if (stored > 0 && (!v->data || max_points != v->data_width))
+        return pcp_fail("voxel data not resident with row width %d", max_points);
+    if (stat_rows > v->stat_rows) {
+        int c1 = v->stat_rows, c2 = v->stat_rows;
+        if (int e = grow(&v->stat, &c1, (size_t)stat_rows, false, c->stream)) return e;
+        if (int e = grow(&v->stat_in, &c2, (size_t)stat_rows, false, c->stream)) return e;
+        v->stat_rows = stat_rows;
+    }
+    if (max_staging != v->stage_rows || max_points != v->stage_width) {   // allocated once, zeroed (:765-770)
+        int cap = 0;
+        PCP_CHECK(hipStreamSynchronize(c->stream));
+        if (v->stage) PCP_CHECK(hipFree(v->stage));
+        v->stage = nullptr;
+        if (int e = grow(&v->stage, &cap, (size_t)max_staging * max_points, true, c->stream)) return e;
+        v->stage_rows = max_staging;
+        v->stage_width = max_points;
+    }
+    int host_counter[16] = {0, max_staging, max_points, stored, stage_everything ? 1 : 0, filter_outliers ? 0 : 1};
+    PCP_CHECK(hipMemcpyAsync(v->counter, host_counter, sizeof(host_counter), hipMemcpyHostToDevice, c->stream));
+    PCP_CHECK(hipMemcpyAsync(v->stat, voxel_stat, (size_t)stat_rows * sizeof(float4), hipMemcpyHostToDevice, c->stream));
+    PCP_CHECK(hipMemcpyAsync(v->stat_in, v->stat, (size_t)stat_rows * sizeof(float4), hipMemcpyDeviceToDevice, c->stream));
+    if (stored > 0) {
+        hipLaunchKernelGGL(k_voxel_stage, dim3(cdiv(stored, 256)), dim3(256), 0, c->stream, v->table, stored, v->data,
+                           v->data_rows, max_points, v->stat, v->stat_in, v->stat_rows, v->stage, max_staging,
+                           stage_everything ? 1 : 0, filter_outliers ? 0 : 1, v->counter);
+        PCP_CHECK(hipGetLastError());
+    }
+    PCP_CHECK(hipMemcpyAsync(host_counter, v->counter, sizeof(host_counter), hipMemcpyDeviceToHost, c->stream));
+    PCP_CHECK(hipMemcpyAsync(voxel_stat, v->stat, (size_t)stat_rows * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
+    PCP_CHECK(hipStreamSynchronize(c->stream));
+    for (int i = 0; i < 16; ++i) counter16[i] = host_counter[i];
+    const int staged = host_counter[0];
+    if (staged < 0 || staged > max_staging) return pcp_fail("corrupt staging counter %d", staged);
+    if (stage_out && staged > 0) {
+        PCP_CHECK(hipMemcpyAsync(stage_out, v->stage, (size_t)staged * max_points * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        PCP_CHECK(hipStreamSynchronize(c->stream));
+    }
+    return 0;
+}
+
+}  // extern "C"

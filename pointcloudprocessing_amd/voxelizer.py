@@ -1,0 +1,303 @@
+"""Host side of the voxel map with the reference's call surface (Voxelizer.py,
+class Voxelizer; file:line citations point there).
+
+Division of labour is the reference's: the device appends the points of a new
+cloud to the voxels already in the table (ComputeShader.prepareDispatchVoxelizer)
+and runs the static/dynamic filter (prepareDispatchVoxelStager); voxels that do
+not exist yet are created here, on the host.  Where the reference inserts new
+voxels one at a time in a Python loop (an O(M) shift of the sorted table per
+voxel, :199-255), this class merges the whole batch into the table with one
+sorted insert; table, data-row numbering, counts and id sets come out the same.
+"""
+import numpy as np
+
+
+class Voxelizer:
+
+    def __init__(self, compute_shader, renderer=None, voxman=None):
+        self.voxel_size = None
+        self.max_points = 1024            # fixed, = row width of the device voxel data (:21)
+        self.compute = compute_shader
+        self.renderer = renderer
+        self.voxman = voxman              # render hand-off object with frameVoxelized(points, colors, separate)
+
+        self.voxel_index = None           # (M, 4) int32: vx, vy, vz, data row; sorted; grows x2
+        self.voxel_data = None            # (M, max_points) int32: [0] count, [1:] point ids
+        self.voxel_stats = None           # (M, 4) float32, by data row
+        self.stored_voxels = None
+
+        self.added_points = None
+        self.added_colors = None
+        self.last_added_point = None
+        self.bigint = 9999999
+
+        self.realloc_needed = None
+        self.prev_stored_voxels = None
+        self.separate_colors = None
+        self.filter_outliers = None
+        self.last_run_realloc = None
+        self.inited = False
+
+    # ------------------------------------------------------------------ life cycle (:48-79, :382-388)
+    def init(self, voxel_size):
+        self.inited = False
+        self.last_added_point = 0
+        self.stored_voxels = 0
+        self.realloc_needed = True
+        self.prev_stored_voxels = -1
+        self.initVoxels()
+        self.last_run_realloc = None
+        self.voxel_size = np.array([voxel_size]).astype(np.float32)
+        self.inited = True
+
+    def initVoxels(self, init_size=100):
+        n = 4096
+        self.voxel_index = np.full((n, 4), self.bigint, dtype=np.int32)
+        self.voxel_data = np.zeros((n, self.max_points), dtype=np.int32)
+        self.voxel_stats = np.zeros((n, 4), dtype=np.float32)
+        self.voxel_stats[:, 0] = 0.5
+
+    def cleanup(self):
+        self.inited = False
+        self.last_added_point = 0
+        self.stored_voxels = 0
+        self.realloc_needed = True
+        self.prev_stored_voxels = -1
+        self.voxel_index = self.voxel_data = self.voxel_stats = None
+        self.added_points = self.added_colors = None
+
+    # ------------------------------------------------------------------ per-frame entry (:81-165)
+    def addPoints(self, np_points, colors, printt=False):
+        self.handleAddingPoints(np_points.astype(np.float32), colors)
+        begin = self.last_added_point - len(np_points)
+        unknown_points, _ = self.compute.prepareDispatchVoxelizer(
+            np_points=np_points, voxel_index=self.voxel_index, voxel_data=self.voxel_data,
+            voxel_size=self.voxel_size, stored_voxel_num=self.stored_voxels, begin_index=begin,
+            max_points_to_store=self.max_points, realloc_needed=self.realloc_needed,
+            prev_stored_voxels=self.prev_stored_voxels, debug=False)
+        self.voxel_stats, voxels_to_render = self.compute.prepareDispatchVoxelStager(
+            self.voxel_index, self.stored_voxels, self.max_points, self.voxel_stats,
+            filter_outliers=self.filter_outliers, stage_everything=False)
+        self.realloc_needed, self.prev_stored_voxels = self.storeUnknownPoints(unknown_points, printt)
+        self.last_run_realloc = self.realloc_needed
+        self._hand_off(voxels_to_render)
+
+    def _hand_off(self, voxels_to_render):
+        if self.renderer is None or self.voxman is None:
+            return
+        for v_slice in voxels_to_render:
+            points, colors = self.getStoredPointsFromVoxelDataSlice(v_slice)
+            self.voxman.frameVoxelized(points, colors, self.separate_colors)
+
+    def refreshVoxelData(self):
+        if not self.last_run_realloc:
+            self.compute.getFullVoxelData(self.stored_voxels, self.max_points, self.voxel_data)
+
+    def stageAllRemaningVoxels(self, ui=None):
+        """:139-165 -- stage until nothing comes back, then ten flush passes (a voxel
+        recovered by its neighbours is only staged by the NEXT dispatch)."""
+        def one_pass():
+            self.voxel_stats, rows = self.compute.prepareDispatchVoxelStager(
+                self.voxel_index, self.stored_voxels, self.max_points, self.voxel_stats,
+                filter_outliers=self.filter_outliers, stage_everything=True)
+            self._hand_off(rows)
+            return rows
+        while True:
+            rows = one_pass()
+            if not np.any(rows):
+                for _ in range(10):
+                    one_pass()
+                break
+
+    # ------------------------------------------------------------------ host half of the map
+    def vectorizedGetVoxelCoord(self, np_points):
+        """:167-168"""
+        return np.ceil(np_points.astype(np.float32) / self.voxel_size).astype(np.int32)
+
+    def getVoxelCoord(self, point):
+        """:391-396"""
+        return np.ceil(point / self.voxel_size).astype(np.int32)
+
+    @staticmethod
+    def _lex_keys(coords):
+        c = np.asarray(coords, dtype=np.int64)
+        if c.size and (np.abs(c).max() >= (1 << 20)):
+            raise RuntimeError("voxel coordinate beyond +-2^20")
+        off = 1 << 20
+        return ((c[:, 0] + off) << 42) | ((c[:, 1] + off) << 21) | (c[:, 2] + off)
+
+    def _grow(self):
+        """:238-252 -- double table, data and statistics."""
+        self.voxel_index = np.vstack([self.voxel_index, np.full_like(self.voxel_index, self.bigint)])
+        self.voxel_data = np.vstack([self.voxel_data, np.zeros_like(self.voxel_data)])
+        fresh = np.zeros_like(self.voxel_stats)
+        fresh[:, 0] = 0.5
+        self.voxel_stats = np.vstack([self.voxel_stats, fresh])
+
+    def storeUnknownPoints(self, unknown_points, printt=False):
+        """:170-306 -> (was_realloc, prev_stored_voxels).  Creates one voxel per
+        distinct coordinate of the unknown points, in lexicographic order of the
+        coordinates (data rows are numbered in that order), each with the count of
+        ALL its points and the ids of the first max_points-1 of them."""
+        n = int(unknown_points[0])
+        prev_stored = self.stored_voxels
+        if n == 0:
+            return False, prev_stored
+        ids = np.sort(unknown_points[1:n + 1])     # the device appends in no particular order
+        coords = self.vectorizedGetVoxelCoord(self.added_points[ids][:, :3])
+        uniq, inverse, counts = np.unique(coords, axis=0, return_inverse=True, return_counts=True)
+        order = np.argsort(inverse.reshape(-1), kind="stable")
+        sorted_ids = ids[order]
+
+        table_keys = self._lex_keys(self.voxel_index[:prev_stored, :3])
+        new_keys = self._lex_keys(uniq)
+        pos = np.searchsorted(table_keys, new_keys)
+        if prev_stored and np.any(table_keys[np.minimum(pos, prev_stored - 1)] == new_keys):
+            raise RuntimeError("Here all unknown points should have a new voxel created")
+
+        new_stored = prev_stored + len(uniq)
+        was_realloc = False
+        while new_stored >= len(self.voxel_index):
+            if not was_realloc and prev_stored > 0:
+                # rows appended on the device since the last read-back would be lost by the
+                # full re-upload that follows a reallocation (:241-244)
+                self.compute.getFullVoxelData(prev_stored, self.max_points, self.voxel_data)
+            self._grow()
+            was_realloc = True
+
+        rows = np.arange(prev_stored, new_stored, dtype=np.int32)
+        entries = np.column_stack([uniq.astype(np.int32), rows])
+        self.voxel_index[:new_stored] = np.insert(self.voxel_index[:prev_stored], pos, entries, axis=0)
+
+        self.voxel_data[rows, 0] = counts
+        keep = np.minimum(counts, self.max_points - 1)
+        starts = np.concatenate([[0], np.cumsum(counts)[:-1]])
+        # scatter the first `keep` ids of every group into its row
+        within = np.arange(len(sorted_ids)) - np.repeat(starts, counts)
+        sel = within < np.repeat(keep, counts)
+        self.voxel_data[np.repeat(rows, counts)[sel], 1 + within[sel]] = sorted_ids[sel]
+        self.stored_voxels = new_stored
+        return was_realloc, prev_stored
+
+    def handleAddingPoints(self, np_points, colors=None):
+        """:398-425 -- the global point store the voxel rows index into."""
+        n = len(np_points)
+        if colors is None:
+            colors = np.full((n, 3), 255)
+        if self.added_points is None:
+            self.added_points = np.empty((n * 2, 4), dtype=np.float32)
+            self.added_colors = np.empty((n * 2, 3), dtype=np.float32)
+        while self.last_added_point + n >= len(self.added_points):
+            self.added_points = np.vstack([self.added_points, np.empty_like(self.added_points)])
+            self.added_colors = np.vstack([self.added_colors, np.empty_like(self.added_colors)])
+        self.added_points[self.last_added_point:self.last_added_point + n, :3] = np_points[:, :3]
+        self.added_colors[self.last_added_point:self.last_added_point + n] = colors
+        self.last_added_point += n
+
+    # ------------------------------------------------------------------ table search on the host (:429-570)
+    def xyzSortedArray(self, np_array):
+        return np_array[np.lexsort((np_array[:, 2], np_array[:, 1], np_array[:, 0]))]
+
+    def bin_search(self, sorted_array_values, value, find_first=True):
+        """:550-570 -> (first/last occurrence or -1, insertion point)."""
+        lo, hi, occ = 0, len(sorted_array_values) - 1, -1
+        while lo <= hi:
+            mid = (lo + hi) // 2
+            v = sorted_array_values[mid]
+            if v == value:
+                occ = mid
+                if find_first:
+                    hi = mid - 1
+                else:
+                    lo = mid + 1
+            elif v < value:
+                lo = mid + 1
+            else:
+                hi = mid - 1
+        return occ, lo
+
+    def bin_search_gpu(self, axis, value, sorted_array_values, find_first, sfrom, sto):
+        """:515-548 -- the shader's variant: search rows [sfrom, sto] on one axis."""
+        occ, _ = self.bin_search(sorted_array_values[sfrom:sto + 1, axis], value, find_first)
+        return -1 if occ == -1 else occ + sfrom
+
+    def findVoxelId(self, xyz_sorted_array, value):
+        """:469-512 -> (position, None) or (-1, insertion position)."""
+        if self.stored_voxels == 0:
+            return -1, 0
+        first_x, ins_x = self.bin_search(xyz_sorted_array[:, 0], value[0], True)
+        if first_x == -1:
+            return -1, ins_x
+        last_x, _ = self.bin_search(xyz_sorted_array[:, 0], value[0], False)
+        ys = xyz_sorted_array[first_x:last_x + 1, 1]
+        first_y, ins_y = self.bin_search(ys, value[1], True)
+        if first_y == -1:
+            return -1, ins_x + ins_y
+        last_y, _ = self.bin_search(ys, value[1], False)
+        first_y, last_y = first_y + first_x, last_y + first_x
+        zs = xyz_sorted_array[first_y:last_y + 1, 2]
+        first_z, ins_z = self.bin_search(zs, value[2], True)
+        if first_z == -1:
+            return -1, ins_x + ins_y + ins_z
+        last_z, _ = self.bin_search(zs, value[2], False)
+        if first_z != last_z:
+            raise RuntimeError("In this impl. no same values should be present")
+        return first_z + first_y, None
+
+    def findVoxelId_gpu(self, xyz_sorted_array, value, lens_data=None):
+        """:432-466 -- the shader's search, bounded by the stored voxel count."""
+        stored = self.stored_voxels if lens_data is None else int(lens_data[1])
+        if stored == 0:
+            return -1
+        fx = self.bin_search_gpu(0, value[0], xyz_sorted_array, True, 0, stored - 1)
+        if fx == -1:
+            return -1
+        lx = self.bin_search_gpu(0, value[0], xyz_sorted_array, False, 0, stored - 1)
+        fy = self.bin_search_gpu(1, value[1], xyz_sorted_array, True, fx, lx)
+        if fy == -1:
+            return -1
+        ly = self.bin_search_gpu(1, value[1], xyz_sorted_array, False, fx, lx)
+        return self.bin_search_gpu(2, value[2], xyz_sorted_array, True, fy, ly)
+
+    # ------------------------------------------------------------------ getters (:379-380, :573-630)
+    def getVoxelDensities(self):
+        return self.voxel_data[:, 0]
+
+    def getStoredCount(self, voxel_data_index):
+        if voxel_data_index >= self.stored_voxels:
+            return None
+        return self.voxel_data[voxel_data_index][0]
+
+    def getStoredPointIndicies(self, voxel_data_index):
+        if voxel_data_index >= self.stored_voxels:
+            return None
+        stored = self.voxel_data[voxel_data_index][0]
+        return self.voxel_data[voxel_data_index][1:min(stored, self.max_points)]
+
+    def getStoredPoints(self, voxel_data_index):
+        if voxel_data_index >= self.stored_voxels:
+            return None
+        stored = self.voxel_data[voxel_data_index][0]
+        ids = self.voxel_data[voxel_data_index][1:min(stored + 1, self.max_points)]
+        return self.added_points[ids][:, :3]
+
+    def getStoredPointsFromVoxelDataSlice(self, slice):
+        stored = slice[0]
+        ids = slice[1:min(stored + 1, self.max_points)]
+        return self.added_points[ids][:, :3], self.added_colors[ids]
+
+    def getStoredVoxelCount(self):
+        return self.stored_voxels
+
+    def getVoxelDataIndexPoint(self, np_point):
+        pos = self.findVoxelId_gpu(self.voxel_index, self.getVoxelCoord(np_point))
+        return None if pos == -1 else self.voxel_index[pos][3]
+
+    def getVoxelDataIndexAt(self, index_into_voxel_index):
+        if index_into_voxel_index >= self.stored_voxels:
+            return None
+        return self.voxel_index[index_into_voxel_index][3]
+
+    def getVoxelPositions(self, normalize=True):
+        coords = self.voxel_index[:, :3]
+        return coords * self.voxel_size if normalize else coords

@@ -1,0 +1,209 @@
+"""Parity of the HIP voxel kernels (through the C ABI) with the reference's own
+Voxelizer output on the KITTI fixture frames, with the CPU restatement, and with
+the known answers of the reference's tests/VoxelizerTest.py.  Voxel coordinates,
+table positions, counts and counters are exact; point ids inside a row and rows
+in the staging buffer are compared as sets (append order is not defined by the
+reference either, tests/VoxelizerTest.py:325-331)."""
+import hashlib
+
+import numpy as np
+import pytest
+
+from oracle import np_voxel as V
+from pointcloudprocessing_amd import PcpError, Voxelizer
+from tests._data import golden, kitti_pair, small_pair
+
+pytestmark = pytest.mark.gpu
+G = golden("ref_voxel.npz")
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def test_voxelizer_reproduces_reference_map_on_kitti(compute):
+    v = Voxelizer(compute, None)
+    v.init(0.5)
+    v.filter_outliers = True
+    for k, frame in enumerate(kitti_pair()):
+        v.addPoints(frame, None)
+        assert v.stored_voxels == int(G[f"stored{k}"]) and len(v.voxel_index) == int(G[f"capacity{k}"])
+    v.refreshVoxelData()
+    s = v.stored_voxels
+    assert np.array_equal(v.voxel_index[:s], G["voxel_index"])
+    assert np.array_equal(v.voxel_data[:s, 0], G["counts"])
+    rows = [np.sort(v.voxel_data[r, 1:min(v.voxel_data[r, 0] + 1, v.max_points)]) for r in range(s)]
+    assert sha(np.concatenate(rows)) == str(G["ids_sha"])
+
+
+def test_dispatch_matches_reference_and_restatement(compute):
+    """tests/VoxelizerTest.py:263-342 (test_gpuCanVoxelize) and :192-261 (test_sameUnknownPoints)."""
+    a, b = kitti_pair()
+    m = V.VoxelMap(0.5)
+    m.add_points(a)
+    ref_data = m.voxel_data.copy()
+    begin = len(a)
+    unknown, dbg = compute.prepareDispatchVoxelizer(
+        np_points=b, voxel_index=m.voxel_index, voxel_data=m.voxel_data, voxel_size=np.array([0.5], np.float32),
+        stored_voxel_num=m.stored, begin_index=begin, max_points_to_store=1024, realloc_needed=True,
+        prev_stored_voxels=-1, debug=True)
+    r_unknown, r_coords, r_entry = V.voxelize_dispatch(b, m.voxel_index, ref_data, 0.5, m.stored, begin, 1024)
+    assert sha(dbg[:, :3].astype(np.int32)) == str(G["coords_sha1"])          # voxel coordinates, exact
+    assert sha(dbg[:, 3].astype(np.int32)) == str(G["entries_sha1"])          # table positions, exact
+    assert np.array_equal(dbg[:, :3].astype(np.int32), r_coords) and np.array_equal(dbg[:, 3].astype(np.int64), r_entry)
+    assert unknown[0] == r_unknown[0] == int(G["unknown_count1"])
+    assert len(unknown) == len(r_unknown) and len(unknown) % 16 == 0 and not unknown[1 + unknown[0]:].any()
+    assert sha(np.sort(unknown[1:1 + unknown[0]])) == str(G["unknown_sorted_sha1"])
+    got = np.zeros_like(ref_data)
+    compute.getFullVoxelData(m.stored, 1024, got)
+    assert np.array_equal(got[:m.stored, 0], ref_data[:m.stored, 0])            # counts
+    for r in range(0, m.stored, 7):
+        k = min(got[r, 0] + 1, 1024)
+        assert np.array_equal(np.sort(got[r, 1:k]), np.sort(ref_data[r, 1:k]))
+
+
+def test_row_overflow_keeps_counting(compute):
+    """More points than a row holds: the count keeps growing, ids stop at max_points - 1."""
+    pts = np.tile(np.array([[0.1, 0.1, 0.1]]), (3000, 1)) + np.linspace(0, 0.3, 3000)[:, None]
+    v = Voxelizer(compute, None)
+    v.init(1.0)
+    v.filter_outliers = False
+    v.addPoints(pts[:5], None)
+    v.addPoints(pts, None)
+    v.refreshVoxelData()
+    assert v.stored_voxels == 1 and v.voxel_data[0, 0] == 3005
+    assert len(np.unique(v.voxel_data[0, 1:1024])) == 1023
+    v.addPoints(pts[:10], None)                                  # the voxel is now ready to stage (0.8)
+    assert v.voxel_stats[0, 2] == np.float32(0.8)
+
+
+def _two_voxels(max_points=1024):
+    voxel_index = np.array([[0, 0, 0, 0], [0, 2, 0, 1]], dtype=np.int32)
+    voxel_data = np.zeros((2, max_points), dtype=np.int32)
+    voxel_data[0, :2] = [1, 1]
+    voxel_data[1, :3] = [2, 2, 3]
+    return voxel_index, voxel_data, np.zeros((2, 4), dtype=np.float32)
+
+
+def _stage(compute, vi, vd, st, stored, **kw):
+    compute.bufferVoxelIndex(vi)
+    compute.fullBufferVoxelData(vd)
+    return compute.prepareDispatchVoxelStager(voxel_index=None, stored_voxel_num=stored, max_points=vd.shape[1],
+                                              voxel_statistics=st, debug=True, **kw)
+
+
+def test_stager_known_answers(compute):
+    """tests/VoxelizerTest.py:345-676"""
+    vi, vd, st = _two_voxels()
+    st[:, 3] = 1.0
+    before = st.copy()
+    st, stage, counter = _stage(compute, vi, vd, st, 2, filter_outliers=True, stage_everything=True, max_staging=512)
+    assert list(counter[0][:6]) == [0, 512, 1024, 2, 1, 0] and np.array_equal(st, before)
+    assert stage.shape == (512, 1024)
+
+    vi, vd, st = _two_voxels()
+    st[0, 0], st[1, 0] = 1.0, 0.91
+    st, stage, counter = _stage(compute, vi, vd, st, 2, filter_outliers=False, stage_everything=False, max_staging=512)
+    assert list(counter[0][:6]) == [0, 512, 1024, 2, 0, 1]
+    assert st[0, 2] == np.float32(0.2) and st[1, 2] == np.float32(0.2)
+    assert np.isclose(st[0, 1], 1.999, atol=0.001) and 2.9 <= st[1, 1] <= 3.0
+
+    vi, vd, st = _two_voxels()
+    vd[0, :4] = [3, 1, 77, 11]
+    st[0, 0], st[1, 0] = 1.0, 0.91
+    st[0, 2] = 0.8
+    st, stage, counter = _stage(compute, vi, vd, st, 2, filter_outliers=False, stage_everything=False, max_staging=512)
+    assert counter[0][0] == 1 and st[0, 3] == 1.0 and st[1, 3] == 0.0
+    assert list(stage[0, :4]) == [3, 1, 77, 11]
+
+    vi, vd, st = _two_voxels()
+    vd[0, :4] = [3, 1, 77, 11]
+    st[:, 2] = 0.8
+    st, stage, counter = _stage(compute, vi, vd, st, 2, filter_outliers=False, stage_everything=False, max_staging=512)
+    assert counter[0][0] == 2 and np.all(st[:, 3] == 1.0)
+    assert list(stage[0, :4]) == [3, 1, 77, 11] and list(stage[1, :3]) == [2, 2, 3]   # same wave: lane order
+
+
+def test_stager_many_voxels(compute):
+    """tests/VoxelizerTest.py:680-794"""
+    n = 300
+    vi = np.zeros((2 * n, 4), dtype=np.int32)
+    vd = np.zeros((2 * n, 1024), dtype=np.int32)
+    st = np.zeros((2 * n, 4), dtype=np.float32)
+    for i in range(n):
+        vi[i, 3] = i
+        vd[i, 0] = i
+        vd[i, 1:1 + i] = 10 + np.arange(i)
+        if i % 5 == 0:
+            vd[i, 1:1024] = i * 100
+            vd[i, 1023] = i
+            vd[i, 0] = 11234
+        vd[i, 1] = i
+        st[i, 2] = 0.8
+    st, stage, counter = _stage(compute, vi, vd, st, n, filter_outliers=False, stage_everything=False, max_staging=512)
+    assert counter[0][0] == n and np.all(st[:n, 3] == 1.0) and np.all(st[n:, 3] == 0.0)
+    seen = set()
+    for i in range(n):
+        src = stage[i][1]
+        seen.add(int(src))
+        k = min(stage[i][0] + 1, 1024)
+        assert stage[i][0] == vd[src][0] and np.array_equal(stage[i][1:k], vd[src][1:k])
+    assert seen == set(range(n))
+
+
+def test_stager_matches_restatement_on_random_states(compute):
+    rng = np.random.default_rng(9)
+    for trial, (filt, everything, max_staging) in enumerate([(True, False, 64), (False, False, 1024), (True, True, 1024),
+                                                             (True, True, 40), (False, True, 1024)]):
+        coords = np.unique(rng.integers(-6, 6, size=(700, 3)), axis=0)
+        n = len(coords)
+        vi = np.column_stack([coords, rng.permutation(n)]).astype(np.int32)
+        vd = np.zeros((n, 64), dtype=np.int32)
+        vd[:, 0] = rng.integers(0, 90, n)
+        vd[:, 1:] = rng.integers(0, 100000, (n, 63))
+        st = np.zeros((n, 4), dtype=np.float32)
+        st[:, 0] = rng.uniform(0.05, 0.99, n)
+        prev = np.where(rng.random(n) < 0.5, vd[:, 0], rng.integers(0, 90, n))
+        st[:, 1] = prev + rng.uniform(0.0, 0.98, n).astype(np.float32)
+        st[:, 2] = rng.choice([0.0, 0.2, 0.8], n, p=[0.6, 0.25, 0.15])
+        st[:, 3] = rng.choice([0.0, 1.0], n, p=[0.85, 0.15])
+        ref = st.copy()
+        r_counter, r_stage = V.voxel_stage(vi, vd, ref, n, 64, filt, everything, max_staging)
+        got = st.copy()
+        got, stage, counter = _stage(compute, vi, vd, got, n, filter_outliers=filt, stage_everything=everything,
+                                     max_staging=max_staging)
+        assert np.array_equal(counter[0][:6], r_counter[:6]), trial
+        k = counter[0][0]
+        if k < max_staging:                                    # no overflow: outcome is fully determined
+            assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), trial
+            key = lambda rows: sorted(tuple(r[:min(r[0] + 1, 64)]) for r in rows)
+            assert key(stage[:k]) == key(r_stage[:k]), trial
+        else:                                                  # which voxels won the race is not defined
+            assert got[:, 3].sum() == ref[:, 3].sum()
+            unstaged = got[:, 3] == ref[:, 3]
+            assert np.array_equal(got[unstaged][:, :3].view(np.uint32), ref[unstaged][:, :3].view(np.uint32))
+
+
+def test_stage_all_remaining_voxels_terminates(compute):
+    a, b = small_pair()
+    v = Voxelizer(compute, None)
+    v.init(0.5)
+    v.filter_outliers = True
+    for f in (a, b, a):
+        v.addPoints(f, None)
+    v.stageAllRemaningVoxels()
+    staged = v.voxel_stats[:v.stored_voxels, 3] == 1.0
+    ready = v.voxel_stats[:v.stored_voxels, 2] > 0.5
+    assert np.array_equal(staged, ready)                       # everything marked ready has been staged
+
+
+def test_voxel_error_paths(compute):
+    with pytest.raises(PcpError):
+        compute.prepareDispatchVoxelStager(None, 5, 17, np.zeros((8, 4), np.float32), True)   # row width mismatch
+    vi, vd, st = _two_voxels()
+    compute.bufferVoxelIndex(vi)
+    compute.fullBufferVoxelData(vd)
+    with pytest.raises(PcpError):
+        compute.prepareDispatchVoxelStager(None, 3, 1024, st, True)                          # stored > table rows
+    with pytest.raises(PcpError):
+        compute.prepareDispatchVoxelizer(np.zeros((0, 3)), vi, vd, np.array([0.5], np.float32), 2, 0, 1024, True, -1)
