@@ -14,7 +14,7 @@
 #include "pcp_host.h"
 
 struct pcp_voxel_state {
-    int4* table = nullptr;   int table_rows = 0;
+    int4* table = nullptr;   int table_rows = 0, table_valid = 0;   // capacity / rows of the last upload
     int* data = nullptr;     int data_rows = 0, data_width = 0;
     float4 *stat = nullptr, *stat_in = nullptr;   int stat_rows = 0;
     int* stage = nullptr;    int stage_rows = 0, stage_width = 0;
@@ -235,6 +235,7 @@ int pcp_voxel_index_upload(pcp_ctx* c, const int32_t* voxel_index, int rows) {
     }
     PCP_CHECK(hipMemcpyAsync(v->table, voxel_index, (size_t)rows * sizeof(int4), hipMemcpyHostToDevice, c->stream));
     PCP_CHECK(hipStreamSynchronize(c->stream));
+    v->table_valid = rows;
     return 0;
 }
 
@@ -290,7 +291,7 @@ int pcp_voxelize(pcp_ctx* c, const float* pts_xyzw, int n, float voxel_size, int
     if (n < 1) return pcp_fail("no points to voxelize");
     if (unknown_len < n + 1) return pcp_fail("unknown list of %d ints cannot hold 1 + %d entries", unknown_len, n);
     if (!(voxel_size > 0.0f)) return pcp_fail("voxel_size must be positive");
-    if (stored < 0 || stored > v->table_rows) return pcp_fail("stored = %d, resident table has %d rows", stored, v->table_rows);
+    if (stored < 0 || stored > v->table_valid) return pcp_fail("stored = %d, resident table has %d rows", stored, v->table_valid);
     if (stored > 0 && (!v->data || max_points != v->data_width))
         return pcp_fail("voxel data not resident with row width %d", max_points);
     if (int e = grow(&v->unknown, &v->unknown_cap, (size_t)n + 1, false, c->stream)) return e;
@@ -322,7 +323,7 @@ int pcp_voxel_stage(pcp_ctx* c, float* voxel_stat, int stat_rows, int stored, in
     pcp_voxel_state* v = c->vox;
     if (!voxel_stat || !counter16) return pcp_fail("null argument");
     if (stat_rows < 1 || max_staging < 1 || max_points < 2) return pcp_fail("bad sizes");
-    if (stored < 0 || stored > v->table_rows) return pcp_fail("stored = %d, resident table has %d rows", stored, v->table_rows);
+    if (stored < 0 || stored > v->table_valid) return pcp_fail("stored = %d, resident table has %d rows", stored, v->table_valid);
     if (stored > 0 && (!v->data || max_points != v->data_width))
         return pcp_fail("voxel data not resident with row width %d", max_points);
     if (stat_rows > v->stat_rows) {
