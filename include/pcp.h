@@ -152,6 +152,12 @@ int pcp_voxel_stage(pcp_ctx* ctx, float* voxel_stat, int stat_rows, int stored, 
                     int filter_outliers, int stage_everything, int max_staging,
                     int32_t* counter16, int32_t* stage_out);
 
+/* The per-ring elevation bands the search prunes with, n_scans x 4 floats:
+ * (sin, cos) of the lowest and (sin, cos) of the highest unit-sphere elevation
+ * among the ring's points; NaN rows mark rings that are never skipped.  For
+ * inspection and tests; no counterpart in the reference. */
+int pcp_ring_stats(pcp_ctx* ctx, float* out);
+
 /* Per-kernel timing of the loop: while enabled, pcp_icp_launch records a HIP
  * event before and after every fused NN + least-squares launch on the
  * context's stream; pcp_profile_read waits for the stream and returns the

@@ -56,6 +56,7 @@ SIGNATURES = {
     "pcp_voxel_data_read": (C.c_int, [_ctx, C.c_int, C.c_int, _i32p]),
     "pcp_voxelize": (C.c_int, [_ctx, _f32p, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, _i32p, C.c_int, _f32p]),
     "pcp_voxel_stage": (C.c_int, [_ctx, _f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _i32p, _i32p]),
+    "pcp_ring_stats": (C.c_int, [_ctx, _f32p]),
     "pcp_profile_enable": (C.c_int, [_ctx, C.c_int]),
     "pcp_profile_read": (C.c_int, [_ctx, _f32p, _i32p]),
     "pcp_timer_start": (C.c_int, [_ctx]),

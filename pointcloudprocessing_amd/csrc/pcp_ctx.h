@@ -30,6 +30,7 @@ struct pcp_ctx {
     float *hint = nullptr, *nn_dist = nullptr;
     uint32_t* nn_idx = nullptr;
     int2* scan = nullptr;
+    float4* ring_stat = nullptr;   // per ring: (sin, cos) of lowest and highest elevation
     float *partials = nullptr, *lvl0 = nullptr, *lvl1 = nullptr;
     float *hb_trace = nullptr, *dx_trace = nullptr;   // max_iter_cap x 64 / x 6
     IcpState* state = nullptr;

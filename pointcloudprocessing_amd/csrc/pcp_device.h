@@ -50,6 +50,7 @@ struct Target {
     const float4* __restrict__ a;    // target points
     const float4* __restrict__ ua;   // unit_sphere(a[i])
     const int2* scan;                // (begin, end_inclusive) per ring, in LDS
+    const float4* stat;              // per ring (sin, cos) of its lowest and highest elevation, in LDS
     int n_a;
     int Z;                           // lens_data.z
     float4 o;
@@ -110,24 +111,72 @@ __device__ __forceinline__ void ring_window(const Target& T, const float4 q, con
     }
 }
 
+// Lower bound on distsq(q, a) over EVERY point a of a ring, from the ring's
+// elevation band.  With u = unit_sphere(a) and the pole e = (0,1,0,0), the angle
+// between u and the query direction is at least the difference of their
+// elevations (triangle inequality on the unit sphere, any dimension), and the
+// distance from q' = q - o' to a ray at angle D from it is at least |q'| sin D.
+// st = (sin, cos) of the band's lowest and (sin, cos) of its highest elevation;
+// (sq, cq) the query's.  The 1e-5 and 0.999 margins are orders of magnitude
+// above the float32 rounding of every quantity involved, so a ring whose
+// bound exceeds the running minimum cannot hold the minimum nor tie it.
+// NaN statistics (set for rings too close to the pole or with undefined unit
+// vectors) make the comparison false: such rings are never skipped.
+__device__ __forceinline__ float ring_lower_bound(const float4 st, const float sq, const float cq,
+                                                  const float rho2) {
+    float sd = 0.0f;
+    if (sq > st.z) sd = sq * st.w - cq * st.z;
+    else if (sq < st.x) sd = st.x * cq - st.y * sq;
+    sd = sd - 1e-5f;
+    return (sd > 0.0f) ? (rho2 * 0.999f) * (sd * sd) : 0.0f;
+}
+
 // findClosestPoint, FunctionalBase.glsl:203-231.  hint is corr[id].w, updated in place.
+// The shader walks rings [from, to) in ascending order and keeps the strict
+// minimum, i.e. the smallest distance, then the lowest ring, then the first
+// window slot.  This routine returns exactly that triple but visits the most
+// promising ring first (the hinted one, else the one with the smallest lower
+// bound) and skips every ring whose lower bound exceeds the running minimum.
 __device__ __forceinline__ int find_closest(const Target& T, const float4 q, float& hint) {
-    const float4 ref = unit_sphere(q, T.o);
+    const float4 v = make_float4(q.x - T.o.x, (q.y - T.o.y) - PCP_LIDAR_OFF_Y, q.z - T.o.z, q.w - T.o.w);
+    const float rho2 = dot4(v, v);
+    const float len = sqrtf(rho2);
+    const float4 ref = make_float4(v.x / len, v.y / len, v.z / len, v.w / len);   // == unit_sphere(q, o)
+    const float sq = ref.y;
+    const float cq = sqrtf(ref.x * ref.x + ref.z * ref.z + ref.w * ref.w);
+    const bool can_prune = cq > 0.05f;          // near the pole the elevation is ill-conditioned
     float mind = PCP_BIG;
-    int glob = 0;
-    int from = 0, to = T.Z;
+    int glob = 0, ring = -1;
+    int from = 0, to = T.Z, first = -1;
     if (hint != -1.0f) {
         const int h = (int)hint;
         from = max(0, h - 2);
         to = min(T.Z, h + 2);
+        if (h >= from && h < to) first = h;
+    } else if (can_prune) {
+        float lo = PCP_BIG;
+        for (int r = from; r < to; ++r) {
+            const float lb = ring_lower_bound(T.stat[r], sq, cq, rho2);
+            if (lb < lo) { lo = lb; first = r; }
+        }
+    }
+    if (first >= 0) {
+        const int2 se = T.scan[first];
+        int best;
+        float d;
+        ring_window<10>(T, q, ref, se.x, se.y, -1, best, d);
+        if (d < mind) { mind = d; glob = best; ring = first; }
     }
     for (int r = from; r < to; ++r) {
+        if (r == first) continue;
+        if (can_prune && ring_lower_bound(T.stat[r], sq, cq, rho2) > mind) continue;
         const int2 se = T.scan[r];
         int best;
         float d;
         ring_window<10>(T, q, ref, se.x, se.y, -1, best, d);
-        if (d < mind) { mind = d; glob = best; hint = (float)r; }
+        if (d < mind || (d == mind && ring >= 0 && r < ring)) { mind = d; glob = best; ring = r; }
     }
+    if (ring >= 0) hint = (float)ring;
     return glob;
 }
 

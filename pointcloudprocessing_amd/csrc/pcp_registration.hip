@@ -42,24 +42,66 @@ __global__ void k_fill(float* __restrict__ p, int n, float v) {
     if (i < n) p[i] = v;
 }
 
-__device__ __forceinline__ void load_scan(int2* s_scan, const int2* __restrict__ scan, int Z) {
-    for (int i = threadIdx.x; i < Z; i += blockDim.x) s_scan[i] = scan[i];
+// LDS image of the ring table: Z float4 elevation bands, then Z int2 (begin, end).
+__device__ __forceinline__ void load_rings(char* smem, const int2* __restrict__ scan,
+                                           const float4* __restrict__ stat, int Z,
+                                           const int2*& s_scan, const float4*& s_stat) {
+    float4* st = reinterpret_cast<float4*>(smem);
+    int2* sc = reinterpret_cast<int2*>(smem + (size_t)Z * sizeof(float4));
+    for (int i = threadIdx.x; i < Z; i += blockDim.x) {
+        sc[i] = scan[i];
+        st[i] = stat[i];
+    }
     __syncthreads();
+    s_scan = sc;
+    s_stat = st;
+}
+
+// Elevation band of every ring: (sin, cos) of the lowest and of the highest
+// unit-vector elevation among its points.  One wave per ring.
+__global__ void __launch_bounds__(64)
+k_ring_stats(const float4* __restrict__ ua, const int2* __restrict__ scan, int Z, float4* __restrict__ stat) {
+    const int r = blockIdx.x;
+    if (r >= Z) return;
+    const int2 se = scan[r];
+    float lo = 2.0f, hi = -2.0f;
+    bool bad = false;
+    for (int p = se.x + (int)threadIdx.x; p <= se.y; p += 64) {
+        const float y = ua[p].y;
+        if (y != y) bad = true;
+        lo = fminf(lo, y);
+        hi = fmaxf(hi, y);
+    }
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) {
+        lo = fminf(lo, __shfl_xor(lo, s, 64));
+        hi = fmaxf(hi, __shfl_xor(hi, s, 64));
+    }
+    bad = __any(bad);
+    if (threadIdx.x == 0) {
+        const float clo = (float)sqrt(fmax(0.0, 1.0 - (double)lo * (double)lo));
+        const float chi = (float)sqrt(fmax(0.0, 1.0 - (double)hi * (double)hi));
+        const float nan = __int_as_float(0x7fc00000);
+        if (bad || !(clo > 0.05f) || !(chi > 0.05f) || lo > hi) stat[r] = make_float4(nan, nan, nan, nan);
+        else stat[r] = make_float4(lo, clo, hi, chi);
+    }
 }
 
 // NearestNeighbourScan.glsl:1-35.  One wave per block = one shader workgroup.
 __global__ void __launch_bounds__(PCP_BLOCK)
 k_nn(const float4* __restrict__ a, const float4* __restrict__ ua, const int2* __restrict__ scan,
-     int n_a, int Z, float4 o, const float4* __restrict__ b, int n_b,
+     const float4* __restrict__ stat, int n_a, int Z, float4 o, const float4* __restrict__ b, int n_b,
      float* __restrict__ hint, uint32_t* __restrict__ idx, float* __restrict__ dist) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    int2* s_scan = reinterpret_cast<int2*>(smem);
-    load_scan(s_scan, scan, Z);
+    const int2* s_scan;
+    const float4* s_stat;
+    load_rings(smem, scan, stat, Z, s_scan, s_stat);
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_b) return;
-    const Target T{a, ua, s_scan, n_a, Z, o};
-    const float4 q = b[i];
-    float h = hint[i];
+    const bool in = i < n_b;
+    const Target T{a, ua, s_scan, s_stat, n_a, Z, o};
+    const float4 q = in ? b[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    float h = in ? hint[i] : -1.0f;
+    if (!in) return;
     const int nn = find_closest(T, q, h);
     hint[i] = h;
     idx[i] = (uint32_t)nn;
@@ -79,13 +121,14 @@ __device__ __forceinline__ int closest_distinct(const Target& T, const float4 q,
 
 __global__ void __launch_bounds__(PCP_BLOCK)
 k_normals(const float4* __restrict__ a, const float4* __restrict__ ua, const int2* __restrict__ scan,
-          int n_a, int Z, float4 o, float4* __restrict__ normals) {
+          const float4* __restrict__ stat, int n_a, int Z, float4 o, float4* __restrict__ normals) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    int2* s_scan = reinterpret_cast<int2*>(smem);
-    load_scan(s_scan, scan, Z);
+    const int2* s_scan;
+    const float4* s_stat;
+    load_rings(smem, scan, stat, Z, s_scan, s_stat);
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_a) return;
-    const Target T{a, ua, s_scan, n_a, Z, o};
+    const Target T{a, ua, s_scan, s_stat, n_a, Z, o};
     // getScanLineOfPoint, NormalShader.glsl:1-10: first ring that contains the point
     int ring = -1;
     for (int r = 0; r < Z; ++r) {
@@ -134,23 +177,24 @@ k_normals(const float4* __restrict__ a, const float4* __restrict__ ua, const int
 template <int MODE, bool F64SRC>
 __global__ void __launch_bounds__(PCP_BLOCK)
 k_ls(const float4* __restrict__ a, const float4* __restrict__ ua, const int2* __restrict__ scan,
-     int n_a, int Z, float4 o, const float4* __restrict__ normals,
+     const float4* __restrict__ stat, int n_a, int Z, float4 o, const float4* __restrict__ normals,
      const float4* __restrict__ b32, const double* __restrict__ b_in, double* __restrict__ b64,
      IcpState* __restrict__ st, int n_b, int debug, float* __restrict__ hint, float* __restrict__ partials,
      float* __restrict__ tiles) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    int2* s_scan = reinterpret_cast<int2*>(smem);
     if (F64SRC) {
         if (st->done) return;
     }
-    load_scan(s_scan, scan, Z);
+    const int2* s_scan;
+    const float4* s_stat;
+    load_rings(smem, scan, stat, Z, s_scan, s_stat);
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const bool in = i < n_b;
     float v[PCP_NVAL];
 #pragma unroll
     for (int k = 0; k < PCP_NVAL; ++k) v[k] = 0.0f;
+    float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
     if (in) {
-        float4 q;
         if (F64SRC) {
             const bool first = st->iter == 0;       // iteration 0 reads the cloud as uploaded
             const double* rd = first ? b_in : b64;
@@ -168,18 +212,19 @@ k_ls(const float4* __restrict__ a, const float4* __restrict__ ua, const int2* __
         } else {
             q = b32[i];
         }
-        const Target T{a, ua, s_scan, n_a, Z, o};
-        int nn;
-        float d;
-        if (debug) {      // debug_info.x >= 1: identity correspondences, LeastSquaresPoint.glsl:78-81
-            nn = i;
-            d = 0.0f;
-        } else {
-            float h = hint[i];
+    }
+    const Target T{a, ua, s_scan, s_stat, n_a, Z, o};
+    int nn = in ? i : 0;      // debug_info.x >= 1: identity correspondences, LeastSquaresPoint.glsl:78-81
+    float d = 0.0f;
+    if (!debug) {
+        float h = in ? hint[i] : -1.0f;
+        if (in) {
             nn = find_closest(T, q, h);
             hint[i] = h;
             d = distsq(q, a[nn]);
         }
+    }
+    if (in) {
         const float4 pa = a[nn];
         if (MODE == PCP_MODE_POINT) ls_point_values(pa, q, d, v);
         else ls_plane_values(pa, q, normals[nn], d, v);
@@ -442,7 +487,7 @@ int ensure_tiles(pcp_ctx* c) {
     return 0;
 }
 
-size_t scan_smem(const pcp_ctx* c) { return (size_t)c->n_scans * sizeof(int2); }
+size_t scan_smem(const pcp_ctx* c) { return (size_t)c->n_scans * (sizeof(int2) + sizeof(float4)); }
 
 int upload_b32(pcp_ctx* c, const float* b_xyzw, int n_b) {
     if (!c->have_target) return pcp_fail("no target: call pcp_set_target first");
@@ -459,7 +504,7 @@ int launch_ls(pcp_ctx* c, int mode, bool f64src, int debug, float* tiles) {
     const size_t sm = scan_smem(c);
     if (mode == PCP_MODE_PLANE && !c->have_normals) return pcp_fail("plane mode needs pcp_normals after pcp_set_target");
     if (debug && n_b > c->n_a) return pcp_fail("identity correspondences need n_b <= n_a");
-#define PCP_LS_ARGS c->a, c->ua, c->scan, c->n_a, c->n_scans, c->origin, c->normals, c->b32, c->b_in, c->b64, c->state, \
+#define PCP_LS_ARGS c->a, c->ua, c->scan, c->ring_stat, c->n_a, c->n_scans, c->origin, c->normals, c->b32, c->b_in, c->b64, c->state, \
                     n_b, debug, c->hint, c->partials, tiles
     if (mode == PCP_MODE_POINT) {
         if (f64src) hipLaunchKernelGGL((k_ls<PCP_MODE_POINT, true>), grid, block, sm, c->stream, PCP_LS_ARGS);
@@ -546,6 +591,7 @@ int pcp_create(int device, int max_points, int max_scans, pcp_ctx** out) {
     A((void**)&c->nn_dist, n * sizeof(float));
     A((void**)&c->nn_idx, n * sizeof(uint32_t));
     A((void**)&c->scan, (size_t)max_scans * sizeof(int2));
+    A((void**)&c->ring_stat, (size_t)max_scans * sizeof(float4));
     A((void**)&c->partials, (size_t)n1 * PCP_PSTRIDE * sizeof(float));
     A((void**)&c->lvl0, (size_t)n2 * PCP_PSTRIDE * sizeof(float));
     A((void**)&c->lvl1, (size_t)n2 * PCP_PSTRIDE * sizeof(float));
@@ -569,7 +615,7 @@ int pcp_destroy(pcp_ctx* c) {
     if (!c) return 0;
     (void)hipSetDevice(c->device);
     if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
-    void* bufs[] = {c->a, c->ua, c->normals, c->b32, c->b_in, c->b64, c->hint, c->nn_dist, c->nn_idx, c->scan,
+    void* bufs[] = {c->a, c->ua, c->normals, c->b32, c->b_in, c->b64, c->hint, c->nn_dist, c->nn_idx, c->scan, c->ring_stat,
                     c->partials, c->lvl0, c->lvl1, c->hb_trace, c->dx_trace, c->state, c->tiles, c->tiles2};
     for (void* p : bufs)
         if (p) (void)hipFree(p);
@@ -606,11 +652,13 @@ int pcp_prepare_resident(pcp_ctx* c, int with_normals) {
     if (!c->have_target) return pcp_fail("no target: call pcp_set_target first");
     hipLaunchKernelGGL(k_unit, dim3(cdiv(c->n_a, 256)), dim3(256), 0, c->stream, c->a, c->ua, c->n_a, c->origin);
     PCP_CHECK(hipGetLastError());
+    hipLaunchKernelGGL(k_ring_stats, dim3(c->n_scans), dim3(64), 0, c->stream, c->ua, c->scan, c->n_scans, c->ring_stat);
+    PCP_CHECK(hipGetLastError());
     if (int e = pcp_reset_hints(c)) return e;
     if (with_normals) {
         if (c->n_scans < 2) return pcp_fail("normals need at least 2 scan lines");
         hipLaunchKernelGGL(k_normals, dim3(cdiv(c->n_a, PCP_BLOCK)), dim3(PCP_BLOCK), scan_smem(c), c->stream, c->a, c->ua,
-                           c->scan, c->n_a, c->n_scans, c->origin, c->normals);
+                           c->scan, c->ring_stat, c->n_a, c->n_scans, c->origin, c->normals);
         PCP_CHECK(hipGetLastError());
         c->have_normals = true;
     }
@@ -649,7 +697,7 @@ int pcp_normals(pcp_ctx* c, float* out_normals) {
     if (!c->have_target) return pcp_fail("no target: call pcp_set_target first");
     if (c->n_scans < 2) return pcp_fail("normals need at least 2 scan lines");
     hipLaunchKernelGGL(k_normals, dim3(cdiv(c->n_a, PCP_BLOCK)), dim3(PCP_BLOCK), scan_smem(c), c->stream, c->a, c->ua, c->scan,
-                       c->n_a, c->n_scans, c->origin, c->normals);
+                       c->ring_stat, c->n_a, c->n_scans, c->origin, c->normals);
     PCP_CHECK(hipGetLastError());
     c->have_normals = true;
     if (out_normals) {
@@ -663,8 +711,8 @@ int pcp_nn(pcp_ctx* c, const float* b_xyzw, int n_b, uint32_t* idx, float* dist2
     if (int e = use(c)) return e;
     if (!idx || !dist2) return pcp_fail("null output");
     if (int e = upload_b32(c, b_xyzw, n_b)) return e;
-    hipLaunchKernelGGL(k_nn, dim3(cdiv(n_b, PCP_BLOCK)), dim3(PCP_BLOCK), scan_smem(c), c->stream, c->a, c->ua, c->scan, c->n_a,
-                       c->n_scans, c->origin, c->b32, n_b, c->hint, c->nn_idx, c->nn_dist);
+    hipLaunchKernelGGL(k_nn, dim3(cdiv(n_b, PCP_BLOCK)), dim3(PCP_BLOCK), scan_smem(c), c->stream, c->a, c->ua, c->scan, c->ring_stat,
+                       c->n_a, c->n_scans, c->origin, c->b32, n_b, c->hint, c->nn_idx, c->nn_dist);
     PCP_CHECK(hipGetLastError());
     PCP_CHECK(hipMemcpyAsync(idx, c->nn_idx, (size_t)n_b * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
     PCP_CHECK(hipMemcpyAsync(dist2, c->nn_dist, (size_t)n_b * sizeof(float), hipMemcpyDeviceToHost, c->stream));
@@ -827,6 +875,15 @@ int pcp_profile_read(pcp_ctx* c, float* ls_ms, int* launches) {
     }
     *ls_ms = total;
     *launches = n;
+    return 0;
+}
+
+int pcp_ring_stats(pcp_ctx* c, float* out) {
+    if (int e = use(c)) return e;
+    if (!out) return pcp_fail("null output");
+    if (!c->have_target) return pcp_fail("no target: call pcp_set_target first");
+    PCP_CHECK(hipMemcpyAsync(out, c->ring_stat, (size_t)c->n_scans * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
+    PCP_CHECK(hipStreamSynchronize(c->stream));
     return 0;
 }
 
