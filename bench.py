@@ -10,8 +10,10 @@ with ring normals, at most 10 iterations, stop at mean|dx| < 1e-6
 (PointcloudIcpContainer.full_pt2pl as UI.py:400 calls it).  One STEP = every
 rank registers its batch of --pairs independent frame pairs: per pair the
 kernel half of preparePointToPlane (unit vectors, normals, hint reset) and the
-whole device-resident iteration loop.  Inputs (target cloud, scan lines,
-float64 source cloud) are resident in HBM before the timed region starts.
+whole device-resident iteration loop, all pairs of the rank batched: one kernel
+launch per iteration covers every pair (pcp_batch_icp_launch).  Inputs (target
+cloud, scan lines, float64 source cloud) are resident in HBM before the timed
+region starts.
 Pairs are independent, so ranks share nothing: weak scaling, no collective in
 the data path (torch.distributed only supplies the barrier and the max).
 """
@@ -27,7 +29,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from pointcloudprocessing_amd import MODE_PLANE, ComputeShader, PointcloudIcpContainer, lidar  # noqa: E402
+from pointcloudprocessing_amd import MODE_PLANE, ComputeShader, IcpBatch, PointcloudIcpContainer, lidar  # noqa: E402
 from pointcloudprocessing_amd._lib import check, f64p  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak
@@ -62,13 +64,6 @@ class Pair:
         check(self.lib.pcp_upload_source(self.ctx, f64p(b64), len(b64)))
         check(self.lib.pcp_synchronize(self.ctx))
 
-    def launch(self):
-        check(self.lib.pcp_prepare_resident(self.ctx, 1))
-        check(self.lib.pcp_icp_launch(self.ctx, MODE_PLANE, MAX_ITER, TOL, 0))
-
-    def sync(self):
-        check(self.lib.pcp_synchronize(self.ctx))
-
     def result(self):
         dx = np.zeros((MAX_ITER, 6), dtype=np.float32)
         it, cv = C.c_int(0), C.c_int(0)
@@ -98,8 +93,7 @@ def main():
     torch.cuda.set_device(local_rank)
 
     def barrier():
-        for p in pairs:
-            p.sync()
+        batch.synchronize()
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
@@ -112,15 +106,18 @@ def main():
         b, R, t = moved_copy(a, 1000 * rank + p)
         pairs.append(Pair(local_rank, a, lines, b))
         truth.append((R, t))
+    batch = IcpBatch([p.cs for p in pairs])
+
+    def step():
+        batch.prepare(True)                                   # unit vectors, ring bands, hints, normals
+        batch.launch(MODE_PLANE, MAX_ITER, TOL, False)        # the whole iteration loop of every pair
 
     for _ in range(args.warmup):
-        for p in pairs:
-            p.launch()
+        step()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        for p in pairs:
-            p.launch()
+        step()
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -146,22 +143,20 @@ def main():
     queries = float(sum(iters)) * n_b * world * args.steps       # every dispatch = n_b fused NN queries
 
     # roofline leg: the same steps again with a HIP event before/after every fused
-    # NN + least-squares launch, on the stream that launch runs on
-    for p in pairs:
-        check(p.lib.pcp_profile_enable(p.ctx, 1))
-    ls_ms, ls_launches = 0.0, 0
+    # NN + least-squares launch, on the stream those launches run on
+    batch.profile(True)
+    ls_ms, ls_launches, ls_points = 0.0, 0, 0
     for _ in range(max(1, min(args.steps, 5))):
-        for p in pairs:
-            p.launch()
-        for p in pairs:
-            ms, n = C.c_float(0), C.c_int(0)
-            check(p.lib.pcp_profile_read(p.ctx, C.byref(ms), C.byref(n)))
-            ls_ms += ms.value
-            ls_launches += n.value
-    for p in pairs:
-        check(p.lib.pcp_profile_enable(p.ctx, 0))
+        step()
+        ms, n, pts = batch.profile_read()
+        ls_ms += ms
+        ls_launches += n
+        ls_points += pts
+    batch.profile(False)
     avg_iters = float(np.mean(iters))
-    alg_bytes = 32.0 * n_b + 32.0 * n_a / avg_iters        # per launch; see DESIGN.md
+    # algorithmic bytes of one launch = 32 B per source point it processed + the 32 B per target
+    # point (point + normal) each pair reads once, spread over that pair's launches
+    alg_bytes = (32.0 * ls_points + 32.0 * n_a * args.pairs * max(1, min(args.steps, 5))) / max(ls_launches, 1)
     avg_launch_s = ls_ms * 1e-3 / max(ls_launches, 1)
     achieved = alg_bytes / avg_launch_s / 1e9
 
@@ -194,8 +189,9 @@ def main():
             "config": {"workload": "configs[1] substitute: point-to-plane ICP with ring normals, <=10 iterations, "
                                    "frame vs rigidly moved + N(0,1cm) copy",
                        "pairs_per_gpu_per_step": args.pairs, "n_a": n_a, "n_b": n_b,
-                       "iterations_per_pair": avg_iters, "parallelism": "independent pairs per GPU"},
-            "roofline": {"bound": "hbm", "kernel": "k_ls<plane> (fused ring-NN + JtJ/Jte + level-1 tree sum)",
+                       "iterations_per_pair": avg_iters, "parallelism": "independent pairs per GPU, batched launches"},
+            "roofline": {"bound": "hbm", "kernel": "k_ls_batch<plane> (fused ring-NN + JtJ/Jte + level-1 tree sum, "
+                                                   "all pairs of the step in one launch)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "avg_launch_us": avg_launch_s * 1e6, "launches_timed": ls_launches,
@@ -203,6 +199,7 @@ def main():
             "cpu_baseline": cpu,
         }
         print(json.dumps(out))
+    batch.close()
     for p in pairs:
         p.cs.cleanup()
     if dist is not None:

@@ -152,6 +152,29 @@ int pcp_voxel_stage(pcp_ctx* ctx, float* voxel_stat, int stat_rows, int stored, 
                     int filter_outliers, int stage_everything, int max_staging,
                     int32_t* counter16, int32_t* stage_out);
 
+/* ---- batches of independent frame pairs -----------------------------------
+ * Consecutive frame pairs of a sequence are independent registrations
+ * (EnvironmentConstructor.py:116-132 calls full_pt2pl once per frame).  A batch
+ * runs the iteration loops of several prepared contexts of one device
+ * together: per iteration ONE launch covers every pair (grid.y = pair) and one
+ * more solves all pairs' 6x6 systems, so a 120k-point cloud no longer leaves
+ * most of the 256 CUs idle.  Results per pair are those of pcp_icp_launch,
+ * bit for bit.  No counterpart in the reference (it has no batching).
+ * The contexts adopt the batch's stream until pcp_batch_destroy. */
+typedef struct pcp_batch pcp_batch;
+int pcp_batch_create(pcp_ctx** ctxs, int n, pcp_batch** out);
+int pcp_batch_destroy(pcp_batch* batch);
+/* pcp_prepare_resident for every context, on the batch's stream. */
+int pcp_batch_prepare(pcp_batch* batch, int with_normals);
+/* pcp_icp_launch for every context (each needs a target, a source, and normals
+ * for the plane mode); fetch with pcp_icp_fetch per context. */
+int pcp_batch_icp_launch(pcp_batch* batch, int mode, int max_iter, float tol, int full_iter);
+int pcp_batch_synchronize(pcp_batch* batch);
+/* As pcp_profile_enable / pcp_profile_read for the batched launches; points
+ * receives the number of source points the timed launches processed. */
+int pcp_batch_profile_enable(pcp_batch* batch, int on);
+int pcp_batch_profile_read(pcp_batch* batch, float* ls_ms, int* launches, long long* points);
+
 /* The per-ring elevation bands the search prunes with, n_scans x 4 floats:
  * (sin, cos) of the lowest and (sin, cos) of the highest unit-sphere elevation
  * among the ring's points; NaN rows mark rings that are never skipped.  For

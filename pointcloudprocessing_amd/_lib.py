@@ -56,6 +56,13 @@ SIGNATURES = {
     "pcp_voxel_data_read": (C.c_int, [_ctx, C.c_int, C.c_int, _i32p]),
     "pcp_voxelize": (C.c_int, [_ctx, _f32p, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, _i32p, C.c_int, _f32p]),
     "pcp_voxel_stage": (C.c_int, [_ctx, _f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _i32p, _i32p]),
+    "pcp_batch_create": (C.c_int, [C.POINTER(_ctx), C.c_int, C.POINTER(C.c_void_p)]),
+    "pcp_batch_destroy": (C.c_int, [C.c_void_p]),
+    "pcp_batch_prepare": (C.c_int, [C.c_void_p, C.c_int]),
+    "pcp_batch_icp_launch": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_int]),
+    "pcp_batch_synchronize": (C.c_int, [C.c_void_p]),
+    "pcp_batch_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
+    "pcp_batch_profile_read": (C.c_int, [C.c_void_p, _f32p, _i32p, C.POINTER(C.c_longlong)]),
     "pcp_ring_stats": (C.c_int, [_ctx, _f32p]),
     "pcp_profile_enable": (C.c_int, [_ctx, C.c_int]),
     "pcp_profile_read": (C.c_int, [_ctx, _f32p, _i32p]),

@@ -270,3 +270,67 @@ class ComputeShader:
             self.cleanup()
         except Exception:
             pass
+
+
+class IcpBatch:
+    """Several prepared ComputeShader contexts of one device whose iteration loops
+    run together: one launch per iteration covers every pair.  Per-pair results
+    are those of ComputeShader.icpRun."""
+
+    def __init__(self, computes):
+        self._lib = _lib.load()
+        self.computes = list(computes)
+        arr = (C.c_void_p * len(self.computes))(*[c._ctx for c in self.computes])
+        self._batch = C.c_void_p()
+        check(self._lib.pcp_batch_create(arr, len(self.computes), C.byref(self._batch)))
+
+    def upload_sources(self, clouds):
+        """float64 (N, 3) source cloud per pair (hints are reset by prepare())."""
+        for c, pts in zip(self.computes, clouds):
+            b = np.ascontiguousarray(np.asarray(pts)[:, :3], dtype=np.float64)
+            check(self._lib.pcp_upload_source(c._ctx, f64p(b), len(b)))
+            check(self._lib.pcp_synchronize(c._ctx))
+
+    def prepare(self, with_normals):
+        check(self._lib.pcp_batch_prepare(self._batch, int(with_normals)))
+
+    def launch(self, mode, iterations, tol=1e-6, full_iter=False):
+        check(self._lib.pcp_batch_icp_launch(self._batch, int(mode), int(iterations), float(tol), int(full_iter)))
+
+    def synchronize(self):
+        check(self._lib.pcp_batch_synchronize(self._batch))
+
+    def results(self, iterations, want_hb=False, want_points=False):
+        """[(dx_trace (iters, 6), converged, hb_trace | None, moved points | None)] per pair."""
+        out = []
+        for c in self.computes:
+            dx = np.zeros((max(iterations, 1), 6), dtype=np.float32)
+            hb = np.zeros((max(iterations, 1), 8, 8), dtype=np.float32) if want_hb else None
+            it, cv = C.c_int(0), C.c_int(0)
+            pts = None
+            if want_points:
+                n = C.c_int(0)
+                pts = np.empty((int(c.lens_data[1]), 3), dtype=np.float64)
+            check(self._lib.pcp_icp_fetch(c._ctx, f32p(dx), f32p(hb), C.byref(it), C.byref(cv), f64p(pts)))
+            out.append((dx[:it.value], bool(cv.value), hb[:it.value] if want_hb else None, pts))
+        return out
+
+    def profile(self, on):
+        check(self._lib.pcp_batch_profile_enable(self._batch, int(on)))
+
+    def profile_read(self):
+        """(summed ms of the batched LS launches that did work, their count, source points they processed)."""
+        ms, n, pts = C.c_float(0), C.c_int(0), C.c_longlong(0)
+        check(self._lib.pcp_batch_profile_read(self._batch, C.byref(ms), C.byref(n), C.byref(pts)))
+        return ms.value, n.value, pts.value
+
+    def close(self):
+        if self._batch:
+            self._lib.pcp_batch_destroy(self._batch)
+            self._batch = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -59,9 +59,8 @@ __device__ __forceinline__ void load_rings(char* smem, const int2* __restrict__ 
 
 // Elevation band of every ring: (sin, cos) of the lowest and of the highest
 // unit-vector elevation among its points.  One wave per ring.
-__global__ void __launch_bounds__(64)
-k_ring_stats(const float4* __restrict__ ua, const int2* __restrict__ scan, int Z, float4* __restrict__ stat) {
-    const int r = blockIdx.x;
+__device__ __forceinline__ void ring_stats_body(const float4* __restrict__ ua, const int2* __restrict__ scan,
+                                                int Z, float4* __restrict__ stat, const int r) {
     if (r >= Z) return;
     const int2 se = scan[r];
     float lo = 2.0f, hi = -2.0f;
@@ -85,6 +84,29 @@ k_ring_stats(const float4* __restrict__ ua, const int2* __restrict__ scan, int Z
         if (bad || !(clo > 0.05f) || !(chi > 0.05f) || lo > hi) stat[r] = make_float4(nan, nan, nan, nan);
         else stat[r] = make_float4(lo, clo, hi, chi);
     }
+}
+
+__global__ void __launch_bounds__(64)
+k_ring_stats(const float4* __restrict__ ua, const int2* __restrict__ scan, int Z, float4* __restrict__ stat) {
+    ring_stats_body(ua, scan, Z, stat, blockIdx.x);
+}
+
+// Prepare-phase kernels for a batch: blockIdx.y / blockIdx.z selects the pair.
+struct PrepArgs {
+    const float4* a; float4* ua; float4* normals; const int2* scan; float4* stat; float* hint;
+    int n_a, Z, max_points; float4 o;
+};
+
+__global__ void k_unit_batch(const PrepArgs* __restrict__ all) {
+    const PrepArgs P = all[blockIdx.y];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < P.n_a) P.ua[i] = unit_sphere(P.a[i], P.o);
+    if (i < P.max_points) P.hint[i] = -1.0f;                  // setInitialScanGuess
+}
+
+__global__ void __launch_bounds__(64) k_ring_stats_batch(const PrepArgs* __restrict__ all) {
+    const PrepArgs P = all[blockIdx.y];
+    ring_stats_body(P.ua, P.scan, P.Z, P.stat, blockIdx.x);
 }
 
 // NearestNeighbourScan.glsl:1-35.  One wave per block = one shader workgroup.
@@ -119,10 +141,9 @@ __device__ __forceinline__ int closest_distinct(const Target& T, const float4 q,
     return best;
 }
 
-__global__ void __launch_bounds__(PCP_BLOCK)
-k_normals(const float4* __restrict__ a, const float4* __restrict__ ua, const int2* __restrict__ scan,
-          const float4* __restrict__ stat, int n_a, int Z, float4 o, float4* __restrict__ normals) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+__device__ __forceinline__ void normals_body(const float4* __restrict__ a, const float4* __restrict__ ua,
+                                             const int2* __restrict__ scan, const float4* __restrict__ stat,
+                                             int n_a, int Z, float4 o, float4* __restrict__ normals, char* smem) {
     const int2* s_scan;
     const float4* s_stat;
     load_rings(smem, scan, stat, Z, s_scan, s_stat);
@@ -168,26 +189,51 @@ k_normals(const float4* __restrict__ a, const float4* __restrict__ ua, const int
     normals[i] = make_float4(nx * sgn, ny * sgn, nz * sgn, 0.0f);
 }
 
+__global__ void __launch_bounds__(PCP_BLOCK)
+k_normals(const float4* __restrict__ a, const float4* __restrict__ ua, const int2* __restrict__ scan,
+          const float4* __restrict__ stat, int n_a, int Z, float4 o, float4* __restrict__ normals) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    normals_body(a, ua, scan, stat, n_a, Z, o, normals, smem);
+}
+
+__global__ void __launch_bounds__(PCP_BLOCK) k_normals_batch(const PrepArgs* __restrict__ all) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const PrepArgs P = all[blockIdx.y];
+    if ((int)(blockIdx.x * PCP_BLOCK) >= P.n_a) return;
+    normals_body(P.a, P.ua, P.scan, P.stat, P.n_a, P.Z, P.o, P.normals, smem);
+}
+
 // LeastSquaresPoint.glsl / LeastSquaresPlane.glsl fused with the first level of
 // ParalellHBSum.glsl: one wave = the 64 consecutive points of one shader
 // workgroup; its tree sum goes to partials[wave].
 //   F64SRC: source points are the float64 cloud of the device loop; the step
 //           left pending by the previous iteration is applied first
 //           (apply_iteration_of_ls, PointcloudIcpContainer.py:172-174).
+struct LsArgs {
+    const float4* a; const float4* ua; const int2* scan; const float4* stat;
+    int n_a, Z; float4 o;
+    const float4* normals; const float4* b32; const double* b_in; double* b64; IcpState* st;
+    int n_b, debug;
+    float* hint; float* partials; float* tiles;
+};
+
 template <int MODE, bool F64SRC>
-__global__ void __launch_bounds__(PCP_BLOCK)
-k_ls(const float4* __restrict__ a, const float4* __restrict__ ua, const int2* __restrict__ scan,
-     const float4* __restrict__ stat, int n_a, int Z, float4 o, const float4* __restrict__ normals,
-     const float4* __restrict__ b32, const double* __restrict__ b_in, double* __restrict__ b64,
-     IcpState* __restrict__ st, int n_b, int debug, float* __restrict__ hint, float* __restrict__ partials,
-     float* __restrict__ tiles) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+__device__ __forceinline__ void ls_body(const LsArgs& A, char* smem) {
+    const float4* __restrict__ a = A.a;
+    const float4* __restrict__ normals = A.normals;
+    const double* __restrict__ b_in = A.b_in;
+    double* __restrict__ b64 = A.b64;
+    IcpState* __restrict__ st = A.st;
+    float* __restrict__ hint = A.hint;
+    float* __restrict__ partials = A.partials;
+    float* __restrict__ tiles = A.tiles;
+    const int n_b = A.n_b, debug = A.debug;
     if (F64SRC) {
         if (st->done) return;
     }
     const int2* s_scan;
     const float4* s_stat;
-    load_rings(smem, scan, stat, Z, s_scan, s_stat);
+    load_rings(smem, A.scan, A.stat, A.Z, s_scan, s_stat);
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const bool in = i < n_b;
     float v[PCP_NVAL];
@@ -210,10 +256,10 @@ k_ls(const float4* __restrict__ a, const float4* __restrict__ ua, const int2* __
             }
             q = make_float4((float)px, (float)py, (float)pz, 0.0f);
         } else {
-            q = b32[i];
+            q = A.b32[i];
         }
     }
-    const Target T{a, ua, s_scan, s_stat, n_a, Z, o};
+    const Target T{a, A.ua, s_scan, s_stat, A.n_a, A.Z, A.o};
     int nn = in ? i : 0;      // debug_info.x >= 1: identity correspondences, LeastSquaresPoint.glsl:78-81
     float d = 0.0f;
     if (!debug) {
@@ -254,6 +300,21 @@ k_ls(const float4* __restrict__ a, const float4* __restrict__ ua, const int2* __
         }
         if (lane < PCP_PSTRIDE) partials[(size_t)wave * PCP_PSTRIDE + lane] = mine;
     }
+}
+
+template <int MODE, bool F64SRC>
+__global__ void __launch_bounds__(PCP_BLOCK) k_ls(const LsArgs A) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    ls_body<MODE, F64SRC>(A, smem);
+}
+
+// The same for a batch of independent pairs: blockIdx.y selects the pair.
+template <int MODE>
+__global__ void __launch_bounds__(PCP_BLOCK) k_ls_batch(const LsArgs* __restrict__ all) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const LsArgs A = all[blockIdx.y];
+    if ((int)(blockIdx.x * PCP_BLOCK) >= A.n_b) return;
+    ls_body<MODE, true>(A, smem);
 }
 
 // 6x6 solve in float64: Gaussian elimination with partial pivoting, the
@@ -334,10 +395,20 @@ __device__ __forceinline__ void rotation_xyz(float xr, float yr, float zr, doubl
 // level-1 partials, then -- when solve != 0 -- the host half of one iteration:
 // dispatchPointToPoint / dispatchPointToPlane (PointcloudIcpContainer.py:24-29,
 // :47-69).  One block of 1024 threads.
-__global__ void __launch_bounds__(1024)
-k_finish(const float* __restrict__ partials, int n1, float* __restrict__ lvl0, float* __restrict__ lvl1,
-         IcpState* __restrict__ st, float* __restrict__ hb_out, float* __restrict__ dx_out,
-         int solve, int mode, int max_iter, float tol, int full_iter) {
+struct FinishArgs {
+    const float* partials; int n1; float* lvl0; float* lvl1;
+    IcpState* st; float* hb_out; float* dx_out;
+};
+
+__device__ __forceinline__ void finish_body(const FinishArgs& F, const int solve, const int mode, const int max_iter,
+                                            const float tol, const int full_iter) {
+    const float* __restrict__ partials = F.partials;
+    float* __restrict__ lvl0 = F.lvl0;
+    float* __restrict__ lvl1 = F.lvl1;
+    IcpState* __restrict__ st = F.st;
+    float* __restrict__ hb_out = F.hb_out;
+    float* __restrict__ dx_out = F.dx_out;
+    const int n1 = F.n1;
     if (solve && st->done) return;
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -425,6 +496,41 @@ k_finish(const float* __restrict__ partials, int n1, float* __restrict__ lvl0, f
     if (it + 1 >= max_iter) st->done = 1;
 }
 
+__global__ void __launch_bounds__(1024)
+k_finish(const FinishArgs F, int solve, int mode, int max_iter, float tol, int full_iter) {
+    finish_body(F, solve, mode, max_iter, tol, full_iter);
+}
+
+__global__ void __launch_bounds__(1024)
+k_finish_batch(const FinishArgs* __restrict__ all, int mode, int max_iter, float tol, int full_iter) {
+    const FinishArgs F = all[blockIdx.x];
+    finish_body(F, 1, mode, max_iter, tol, full_iter);
+}
+
+__global__ void k_apply_pending_batch(const LsArgs* __restrict__ all) {
+    const LsArgs A = all[blockIdx.y];
+    if (!A.st->pending) return;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= A.n_b) return;
+    double* b64 = A.b64;
+    const IcpState* st = A.st;
+    const double px = b64[3 * (size_t)i + 0], py = b64[3 * (size_t)i + 1], pz = b64[3 * (size_t)i + 2];
+    b64[3 * (size_t)i + 0] = ((st->R[0] * px + st->R[1] * py) + st->R[2] * pz) - st->t[0];
+    b64[3 * (size_t)i + 1] = ((st->R[3] * px + st->R[4] * py) + st->R[5] * pz) - st->t[1];
+    b64[3 * (size_t)i + 2] = ((st->R[6] * px + st->R[7] * py) + st->R[8] * pz) - st->t[2];
+}
+
+__global__ void k_state_batch(const LsArgs* __restrict__ all, int n, int reset) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    IcpState* st = all[p].st;
+    if (reset) {
+        st->pending = 0; st->iter = 0; st->done = 0; st->converged = 0; st->singular = 0;
+    } else {
+        st->pending = 0;
+    }
+}
+
 // Applies the step still pending after the last dispatch.
 __global__ void k_apply_pending(double* __restrict__ b64, int n_b, IcpState* __restrict__ st) {
     if (!st->pending) return;
@@ -498,31 +604,48 @@ int upload_b32(pcp_ctx* c, const float* b_xyzw, int n_b) {
     return 0;
 }
 
-int launch_ls(pcp_ctx* c, int mode, bool f64src, int debug, float* tiles) {
-    const int n_b = c->n_b;
-    const dim3 grid(cdiv(n_b, PCP_BLOCK)), block(PCP_BLOCK);
-    const size_t sm = scan_smem(c);
+LsArgs ls_args(const pcp_ctx* c, int debug, float* tiles) {
+    LsArgs A;
+    A.a = c->a; A.ua = c->ua; A.scan = c->scan; A.stat = c->ring_stat;
+    A.n_a = c->n_a; A.Z = c->n_scans; A.o = c->origin;
+    A.normals = c->normals; A.b32 = c->b32; A.b_in = c->b_in; A.b64 = c->b64; A.st = c->state;
+    A.n_b = c->n_b; A.debug = debug;
+    A.hint = c->hint; A.partials = c->partials; A.tiles = tiles;
+    return A;
+}
+
+FinishArgs finish_args(const pcp_ctx* c) {
+    FinishArgs F;
+    F.partials = c->partials; F.n1 = cdiv(c->n_b, 64); F.lvl0 = c->lvl0; F.lvl1 = c->lvl1;
+    F.st = c->state; F.hb_out = c->hb_trace; F.dx_out = c->dx_trace;
+    return F;
+}
+
+int check_ls(const pcp_ctx* c, int mode, int debug) {
+    if (mode != PCP_MODE_POINT && mode != PCP_MODE_PLANE) return pcp_fail("unknown mode %d", mode);
     if (mode == PCP_MODE_PLANE && !c->have_normals) return pcp_fail("plane mode needs pcp_normals after pcp_set_target");
-    if (debug && n_b > c->n_a) return pcp_fail("identity correspondences need n_b <= n_a");
-#define PCP_LS_ARGS c->a, c->ua, c->scan, c->ring_stat, c->n_a, c->n_scans, c->origin, c->normals, c->b32, c->b_in, c->b64, c->state, \
-                    n_b, debug, c->hint, c->partials, tiles
+    if (debug && c->n_b > c->n_a) return pcp_fail("identity correspondences need n_b <= n_a");
+    return 0;
+}
+
+int launch_ls(pcp_ctx* c, int mode, bool f64src, int debug, float* tiles) {
+    if (int e = check_ls(c, mode, debug)) return e;
+    const dim3 grid(cdiv(c->n_b, PCP_BLOCK)), block(PCP_BLOCK);
+    const size_t sm = scan_smem(c);
+    const LsArgs A = ls_args(c, debug, tiles);
     if (mode == PCP_MODE_POINT) {
-        if (f64src) hipLaunchKernelGGL((k_ls<PCP_MODE_POINT, true>), grid, block, sm, c->stream, PCP_LS_ARGS);
-        else hipLaunchKernelGGL((k_ls<PCP_MODE_POINT, false>), grid, block, sm, c->stream, PCP_LS_ARGS);
-    } else if (mode == PCP_MODE_PLANE) {
-        if (f64src) hipLaunchKernelGGL((k_ls<PCP_MODE_PLANE, true>), grid, block, sm, c->stream, PCP_LS_ARGS);
-        else hipLaunchKernelGGL((k_ls<PCP_MODE_PLANE, false>), grid, block, sm, c->stream, PCP_LS_ARGS);
+        if (f64src) hipLaunchKernelGGL((k_ls<PCP_MODE_POINT, true>), grid, block, sm, c->stream, A);
+        else hipLaunchKernelGGL((k_ls<PCP_MODE_POINT, false>), grid, block, sm, c->stream, A);
     } else {
-        return pcp_fail("unknown mode %d", mode);
+        if (f64src) hipLaunchKernelGGL((k_ls<PCP_MODE_PLANE, true>), grid, block, sm, c->stream, A);
+        else hipLaunchKernelGGL((k_ls<PCP_MODE_PLANE, false>), grid, block, sm, c->stream, A);
     }
-#undef PCP_LS_ARGS
     PCP_CHECK(hipGetLastError());
     return 0;
 }
 
 int launch_finish(pcp_ctx* c, int solve, int mode, int max_iter, float tol, int full_iter) {
-    hipLaunchKernelGGL(k_finish, dim3(1), dim3(1024), 0, c->stream, c->partials, cdiv(c->n_b, 64),
-                       c->lvl0, c->lvl1, c->state, c->hb_trace, c->dx_trace, solve, mode, max_iter, tol,
+    hipLaunchKernelGGL(k_finish, dim3(1), dim3(1024), 0, c->stream, finish_args(c), solve, mode, max_iter, tol,
                        full_iter);
     PCP_CHECK(hipGetLastError());
     return 0;
@@ -884,6 +1007,202 @@ int pcp_ring_stats(pcp_ctx* c, float* out) {
     if (!c->have_target) return pcp_fail("no target: call pcp_set_target first");
     PCP_CHECK(hipMemcpyAsync(out, c->ring_stat, (size_t)c->n_scans * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
     PCP_CHECK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+// ---- batches of independent pairs ---------------------------------------------------------
+
+struct pcp_batch {
+    int device = 0;
+    std::vector<pcp_ctx*> ctxs;
+    hipStream_t stream = nullptr;
+    LsArgs *ls_host = nullptr, *ls_dev = nullptr;            // pinned host mirror / device array
+    FinishArgs *fin_host = nullptr, *fin_dev = nullptr;
+    PrepArgs *prep_host = nullptr, *prep_dev = nullptr;
+    bool profile = false;
+    std::vector<hipEvent_t> prof_events;
+    int prof_used = 0;
+    int run_max_iter = 0;
+};
+
+int pcp_batch_destroy(pcp_batch* b) {
+    if (!b) return 0;
+    (void)hipSetDevice(b->device);
+    if (b->stream) (void)hipStreamSynchronize(b->stream);
+    for (pcp_ctx* c : b->ctxs) c->stream = c->own_stream;
+    for (hipEvent_t ev : b->prof_events) (void)hipEventDestroy(ev);
+    if (b->ls_host) (void)hipHostFree(b->ls_host);
+    if (b->fin_host) (void)hipHostFree(b->fin_host);
+    if (b->prep_host) (void)hipHostFree(b->prep_host);
+    if (b->prep_dev) (void)hipFree(b->prep_dev);
+    if (b->ls_dev) (void)hipFree(b->ls_dev);
+    if (b->fin_dev) (void)hipFree(b->fin_dev);
+    if (b->stream) (void)hipStreamDestroy(b->stream);
+    delete b;
+    return 0;
+}
+
+int pcp_batch_create(pcp_ctx** ctxs, int n, pcp_batch** out) {
+    if (!out) return pcp_fail("null out pointer");
+    *out = nullptr;
+    if (!ctxs || n < 1 || n > 65535) return pcp_fail("a batch holds 1..65535 contexts");
+    for (int i = 0; i < n; ++i) {
+        if (!ctxs[i]) return pcp_fail("null context in batch");
+        if (ctxs[i]->device != ctxs[0]->device) return pcp_fail("all contexts of a batch must live on one device");
+        for (int j = 0; j < i; ++j)
+            if (ctxs[j] == ctxs[i]) return pcp_fail("context listed twice in a batch");
+    }
+    PCP_CHECK(hipSetDevice(ctxs[0]->device));
+    pcp_batch* b = new pcp_batch();
+    b->device = ctxs[0]->device;
+    hipError_t e = hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipHostMalloc((void**)&b->ls_host, (size_t)n * sizeof(LsArgs));
+    if (e == hipSuccess) e = hipHostMalloc((void**)&b->fin_host, (size_t)n * sizeof(FinishArgs));
+    if (e == hipSuccess) e = hipMalloc((void**)&b->ls_dev, (size_t)n * sizeof(LsArgs));
+    if (e == hipSuccess) e = hipMalloc((void**)&b->fin_dev, (size_t)n * sizeof(FinishArgs));
+    if (e == hipSuccess) e = hipHostMalloc((void**)&b->prep_host, (size_t)n * sizeof(PrepArgs));
+    if (e == hipSuccess) e = hipMalloc((void**)&b->prep_dev, (size_t)n * sizeof(PrepArgs));
+    if (e != hipSuccess) {
+        pcp_fail("pcp_batch_create: %s", hipGetErrorString(e));
+        pcp_batch_destroy(b);
+        return 1;
+    }
+    for (int i = 0; i < n; ++i) {
+        PCP_CHECK(hipStreamSynchronize(ctxs[i]->stream));      // work queued on the old stream comes first
+        ctxs[i]->stream = b->stream;
+        b->ctxs.push_back(ctxs[i]);
+    }
+    *out = b;
+    return 0;
+}
+
+int pcp_batch_prepare(pcp_batch* b, int with_normals) {
+    if (!b) return pcp_fail("null batch");
+    PCP_CHECK(hipSetDevice(b->device));
+    const int n = (int)b->ctxs.size();
+    int max_na = 0, max_pts = 0, max_scans = 0;
+    PCP_CHECK(hipStreamSynchronize(b->stream));      // the pinned mirror may still be in flight
+    for (int i = 0; i < n; ++i) {
+        pcp_ctx* c = b->ctxs[i];
+        if (!c->have_target) return pcp_fail("pair %d: no target", i);
+        if (with_normals && c->n_scans < 2) return pcp_fail("pair %d: normals need at least 2 scan lines", i);
+        PrepArgs P;
+        P.a = c->a; P.ua = c->ua; P.normals = c->normals; P.scan = c->scan; P.stat = c->ring_stat; P.hint = c->hint;
+        P.n_a = c->n_a; P.Z = c->n_scans; P.max_points = c->max_points; P.o = c->origin;
+        b->prep_host[i] = P;
+        max_na = c->n_a > max_na ? c->n_a : max_na;
+        max_pts = c->max_points > max_pts ? c->max_points : max_pts;
+        max_scans = c->n_scans > max_scans ? c->n_scans : max_scans;
+    }
+    PCP_CHECK(hipMemcpyAsync(b->prep_dev, b->prep_host, (size_t)n * sizeof(PrepArgs), hipMemcpyHostToDevice, b->stream));
+    hipLaunchKernelGGL(k_unit_batch, dim3(cdiv(max_pts, 256), n), dim3(256), 0, b->stream, b->prep_dev);
+    PCP_CHECK(hipGetLastError());
+    hipLaunchKernelGGL(k_ring_stats_batch, dim3(max_scans, n), dim3(64), 0, b->stream, b->prep_dev);
+    PCP_CHECK(hipGetLastError());
+    if (with_normals) {
+        const size_t sm = (size_t)max_scans * (sizeof(int2) + sizeof(float4));
+        hipLaunchKernelGGL(k_normals_batch, dim3(cdiv(max_na, PCP_BLOCK), n), dim3(PCP_BLOCK), sm, b->stream, b->prep_dev);
+        PCP_CHECK(hipGetLastError());
+        for (pcp_ctx* c : b->ctxs) c->have_normals = true;
+    }
+    return 0;
+}
+
+int pcp_batch_icp_launch(pcp_batch* b, int mode, int max_iter, float tol, int full_iter) {
+    if (!b) return pcp_fail("null batch");
+    PCP_CHECK(hipSetDevice(b->device));
+    if (max_iter < 0 || max_iter > pcp_ctx::max_iter_cap)
+        return pcp_fail("max_iter = %d outside [0, %d]", max_iter, pcp_ctx::max_iter_cap);
+    const int n = (int)b->ctxs.size();
+    int max_nb = 0, max_scans = 0;
+    // the pinned mirrors may still be read by the previous launch's copy
+    PCP_CHECK(hipStreamSynchronize(b->stream));
+    for (int i = 0; i < n; ++i) {
+        pcp_ctx* c = b->ctxs[i];
+        if (!c->have_target) return pcp_fail("pair %d: no target", i);
+        if (c->n_b < 1) return pcp_fail("pair %d: no source", i);
+        if (int e = check_ls(c, mode, 0)) return e;
+        b->ls_host[i] = ls_args(c, 0, nullptr);
+        b->fin_host[i] = finish_args(c);
+        max_nb = c->n_b > max_nb ? c->n_b : max_nb;
+        max_scans = c->n_scans > max_scans ? c->n_scans : max_scans;
+        c->run_mode = mode;
+        c->run_max_iter = max_iter;
+    }
+    PCP_CHECK(hipMemcpyAsync(b->ls_dev, b->ls_host, (size_t)n * sizeof(LsArgs), hipMemcpyHostToDevice, b->stream));
+    PCP_CHECK(hipMemcpyAsync(b->fin_dev, b->fin_host, (size_t)n * sizeof(FinishArgs), hipMemcpyHostToDevice, b->stream));
+    hipLaunchKernelGGL(k_state_batch, dim3(cdiv(n, 64)), dim3(64), 0, b->stream, b->ls_dev, n, 1);
+    PCP_CHECK(hipGetLastError());
+    if (max_iter == 0)
+        for (pcp_ctx* c : b->ctxs)
+            PCP_CHECK(hipMemcpyAsync(c->b64, c->b_in, (size_t)c->n_b * 3 * sizeof(double), hipMemcpyDeviceToDevice, b->stream));
+    const dim3 grid(cdiv(max_nb, PCP_BLOCK), n), block(PCP_BLOCK);
+    const size_t sm = (size_t)max_scans * (sizeof(int2) + sizeof(float4));
+    b->prof_used = 0;
+    b->run_max_iter = max_iter;
+    for (int it = 0; it < max_iter; ++it) {
+        if (b->profile) {
+            while ((int)b->prof_events.size() < 2 * (it + 1)) {
+                hipEvent_t ev;
+                PCP_CHECK(hipEventCreate(&ev));
+                b->prof_events.push_back(ev);
+            }
+            PCP_CHECK(hipEventRecord(b->prof_events[2 * it], b->stream));
+        }
+        if (mode == PCP_MODE_POINT) hipLaunchKernelGGL((k_ls_batch<PCP_MODE_POINT>), grid, block, sm, b->stream, b->ls_dev);
+        else hipLaunchKernelGGL((k_ls_batch<PCP_MODE_PLANE>), grid, block, sm, b->stream, b->ls_dev);
+        PCP_CHECK(hipGetLastError());
+        if (b->profile) {
+            PCP_CHECK(hipEventRecord(b->prof_events[2 * it + 1], b->stream));
+            b->prof_used = it + 1;
+        }
+        hipLaunchKernelGGL(k_finish_batch, dim3(n), dim3(1024), 0, b->stream, b->fin_dev, mode, max_iter, tol, full_iter);
+        PCP_CHECK(hipGetLastError());
+    }
+    hipLaunchKernelGGL(k_apply_pending_batch, dim3(cdiv(max_nb, 256), n), dim3(256), 0, b->stream, b->ls_dev);
+    PCP_CHECK(hipGetLastError());
+    hipLaunchKernelGGL(k_state_batch, dim3(cdiv(n, 64)), dim3(64), 0, b->stream, b->ls_dev, n, 0);
+    PCP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int pcp_batch_synchronize(pcp_batch* b) {
+    if (!b) return pcp_fail("null batch");
+    PCP_CHECK(hipSetDevice(b->device));
+    PCP_CHECK(hipStreamSynchronize(b->stream));
+    return 0;
+}
+
+int pcp_batch_profile_enable(pcp_batch* b, int on) {
+    if (!b) return pcp_fail("null batch");
+    b->profile = on != 0;
+    return 0;
+}
+
+int pcp_batch_profile_read(pcp_batch* b, float* ls_ms, int* launches, long long* points) {
+    if (!b) return pcp_fail("null batch");
+    if (!ls_ms || !launches || !points) return pcp_fail("null output");
+    PCP_CHECK(hipSetDevice(b->device));
+    PCP_CHECK(hipStreamSynchronize(b->stream));
+    // a launch did work for the pairs that had not finished before it
+    int longest = 0;
+    long long pts = 0;
+    for (pcp_ctx* c : b->ctxs) {
+        IcpState st;
+        PCP_CHECK(hipMemcpy(&st, c->state, sizeof(IcpState), hipMemcpyDeviceToHost));
+        longest = st.iter > longest ? st.iter : longest;
+        pts += (long long)st.iter * c->n_b;
+    }
+    const int n = longest < b->prof_used ? longest : b->prof_used;
+    float total = 0.f;
+    for (int i = 0; i < n; ++i) {
+        float ms = 0.f;
+        PCP_CHECK(hipEventElapsedTime(&ms, b->prof_events[2 * i], b->prof_events[2 * i + 1]));
+        total += ms;
+    }
+    *ls_ms = total;
+    *launches = n;
+    *points = pts;
     return 0;
 }
 

@@ -210,6 +210,37 @@ def test_stepwise_protocol_equals_device_loop(compute):
     _pose_close(t1, R1, t2, R2)
 
 
+def test_batched_pairs_equal_single_pair_runs():
+    """pcp_batch_icp_launch on three pairs of different sizes (one of them converging early)
+    reproduces pcp_icp_run pair by pair, bit for bit."""
+    from pointcloudprocessing_amd import ComputeShader, IcpBatch, lidar
+    a, b = small_pair()
+    a2 = lidar.synthetic_scan(5, rings=21, steps=400)
+    pairs = [(a, b), (a2, (lidar.rotation_xyz(0.003, 0.004, -0.002) @ a2.T).T + 0.02), (a, a + 1e-9)]
+    for mode, iters in ((MODE_PLANE, 9), (MODE_POINT, 5)):
+        singles, computes = [], []
+        for ta, tb in pairs:
+            cs = ComputeShader(maxPointsPerCloud=max(len(ta), len(tb)), maxScans=100)
+            icp = PointcloudIcpContainer(cs)
+            (icp.preparePointToPlane if mode == MODE_PLANE else icp.preparePointToPoint)(ta, ORIGIN, tb)
+            singles.append(cs.icpRun(tb, mode, iters, want_hb=True, want_points=True))
+            computes.append(cs)
+        batch = IcpBatch(computes)
+        batch.upload_sources([tb for _, tb in pairs])
+        batch.prepare(mode == MODE_PLANE)
+        batch.launch(mode, iters)
+        got = batch.results(iters, want_hb=True, want_points=True)
+        for (dx, conv, hb, pts), (rdx, rconv, rhb, rpts) in zip(got, singles):
+            assert conv == rconv and len(dx) == len(rdx)
+            assert np.array_equal(bits(dx), bits(rdx)) and np.array_equal(bits(hb), bits(rhb))
+            assert np.array_equal(pts, rpts)
+        if mode == MODE_PLANE:
+            assert got[2][1] and len(got[2][0]) < iters          # the identical pair stops early
+        batch.close()
+        for cs in computes:
+            cs.cleanup()
+
+
 # ------------------------------------------------------------------------------ errors
 def test_error_paths(compute):
     from pointcloudprocessing_amd import PcpError
