@@ -77,7 +77,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--pairs", type=int, default=8, help="independent frame pairs per GPU per step")
+    ap.add_argument("--pairs", type=int, default=16, help="independent frame pairs per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 

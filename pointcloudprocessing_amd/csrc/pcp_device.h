@@ -134,9 +134,11 @@ __device__ __forceinline__ float ring_lower_bound(const float4 st, const float s
 // findClosestPoint, FunctionalBase.glsl:203-231.  hint is corr[id].w, updated in place.
 // The shader walks rings [from, to) in ascending order and keeps the strict
 // minimum, i.e. the smallest distance, then the lowest ring, then the first
-// window slot.  This routine returns exactly that triple but visits the most
-// promising ring first (the hinted one, else the one with the smallest lower
-// bound) and skips every ring whose lower bound exceeds the running minimum.
+// window slot.  That triple does not depend on the order of the visits, so this
+// routine starts at the most promising ring (the hinted one, else the one whose
+// elevation band is nearest to the query), works outwards from it so that the
+// running minimum tightens early, and skips every ring whose lower bound exceeds
+// that minimum.
 __device__ __forceinline__ int find_closest(const Target& T, const float4 q, float& hint) {
     const float4 v = make_float4(q.x - T.o.x, (q.y - T.o.y) - PCP_LIDAR_OFF_Y, q.z - T.o.z, q.w - T.o.w);
     const float rho2 = dot4(v, v);
@@ -147,28 +149,23 @@ __device__ __forceinline__ int find_closest(const Target& T, const float4 q, flo
     const bool can_prune = cq > 0.05f;          // near the pole the elevation is ill-conditioned
     float mind = PCP_BIG;
     int glob = 0, ring = -1;
-    int from = 0, to = T.Z, first = -1;
+    int from = 0, to = T.Z, centre = 0;
     if (hint != -1.0f) {
         const int h = (int)hint;
         from = max(0, h - 2);
         to = min(T.Z, h + 2);
-        if (h >= from && h < to) first = h;
+        centre = min(max(h, from), to - 1);
     } else if (can_prune) {
         float lo = PCP_BIG;
         for (int r = from; r < to; ++r) {
             const float lb = ring_lower_bound(T.stat[r], sq, cq, rho2);
-            if (lb < lo) { lo = lb; first = r; }
+            if (lb < lo) { lo = lb; centre = r; }
         }
     }
-    if (first >= 0) {
-        const int2 se = T.scan[first];
-        int best;
-        float d;
-        ring_window<10>(T, q, ref, se.x, se.y, -1, best, d);
-        if (d < mind) { mind = d; glob = best; ring = first; }
-    }
-    for (int r = from; r < to; ++r) {
-        if (r == first) continue;
+    const int span = to - from;
+    for (int k = 0; k <= 2 * span; ++k) {
+        const int r = centre + ((k & 1) ? (k + 1) / 2 : -(k / 2));      // c, c+1, c-1, c+2, c-2, ...
+        if (r < from || r >= to) continue;
         if (can_prune && ring_lower_bound(T.stat[r], sq, cq, rho2) > mind) continue;
         const int2 se = T.scan[r];
         int best;

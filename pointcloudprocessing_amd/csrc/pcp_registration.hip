@@ -606,6 +606,7 @@ int upload_b32(pcp_ctx* c, const float* b_xyzw, int n_b) {
 
 LsArgs ls_args(const pcp_ctx* c, int debug, float* tiles) {
     LsArgs A;
+    memset(&A, 0, sizeof(A));          // padding bytes too: descriptors are compared with memcmp
     A.a = c->a; A.ua = c->ua; A.scan = c->scan; A.stat = c->ring_stat;
     A.n_a = c->n_a; A.Z = c->n_scans; A.o = c->origin;
     A.normals = c->normals; A.b32 = c->b32; A.b_in = c->b_in; A.b64 = c->b64; A.st = c->state;
@@ -616,6 +617,7 @@ LsArgs ls_args(const pcp_ctx* c, int debug, float* tiles) {
 
 FinishArgs finish_args(const pcp_ctx* c) {
     FinishArgs F;
+    memset(&F, 0, sizeof(F));
     F.partials = c->partials; F.n1 = cdiv(c->n_b, 64); F.lvl0 = c->lvl0; F.lvl1 = c->lvl1;
     F.st = c->state; F.hb_out = c->hb_trace; F.dx_out = c->dx_trace;
     return F;
@@ -1019,6 +1021,9 @@ struct pcp_batch {
     LsArgs *ls_host = nullptr, *ls_dev = nullptr;            // pinned host mirror / device array
     FinishArgs *fin_host = nullptr, *fin_dev = nullptr;
     PrepArgs *prep_host = nullptr, *prep_dev = nullptr;
+    std::vector<LsArgs> ls_sent;            // what the device arrays hold (skip the copy when unchanged)
+    std::vector<FinishArgs> fin_sent;
+    std::vector<PrepArgs> prep_sent;
     bool profile = false;
     std::vector<hipEvent_t> prof_events;
     int prof_used = 0;
@@ -1081,20 +1086,26 @@ int pcp_batch_prepare(pcp_batch* b, int with_normals) {
     PCP_CHECK(hipSetDevice(b->device));
     const int n = (int)b->ctxs.size();
     int max_na = 0, max_pts = 0, max_scans = 0;
-    PCP_CHECK(hipStreamSynchronize(b->stream));      // the pinned mirror may still be in flight
+    std::vector<PrepArgs> want((size_t)n);
     for (int i = 0; i < n; ++i) {
         pcp_ctx* c = b->ctxs[i];
         if (!c->have_target) return pcp_fail("pair %d: no target", i);
         if (with_normals && c->n_scans < 2) return pcp_fail("pair %d: normals need at least 2 scan lines", i);
         PrepArgs P;
+        memset(&P, 0, sizeof(P));
         P.a = c->a; P.ua = c->ua; P.normals = c->normals; P.scan = c->scan; P.stat = c->ring_stat; P.hint = c->hint;
         P.n_a = c->n_a; P.Z = c->n_scans; P.max_points = c->max_points; P.o = c->origin;
-        b->prep_host[i] = P;
+        want[i] = P;
         max_na = c->n_a > max_na ? c->n_a : max_na;
         max_pts = c->max_points > max_pts ? c->max_points : max_pts;
         max_scans = c->n_scans > max_scans ? c->n_scans : max_scans;
     }
-    PCP_CHECK(hipMemcpyAsync(b->prep_dev, b->prep_host, (size_t)n * sizeof(PrepArgs), hipMemcpyHostToDevice, b->stream));
+    if (b->prep_sent.size() != want.size() || memcmp(b->prep_sent.data(), want.data(), want.size() * sizeof(PrepArgs)) != 0) {
+        PCP_CHECK(hipStreamSynchronize(b->stream));      // the pinned mirror may still be in flight
+        memcpy(b->prep_host, want.data(), want.size() * sizeof(PrepArgs));
+        PCP_CHECK(hipMemcpyAsync(b->prep_dev, b->prep_host, (size_t)n * sizeof(PrepArgs), hipMemcpyHostToDevice, b->stream));
+        b->prep_sent = want;
+    }
     hipLaunchKernelGGL(k_unit_batch, dim3(cdiv(max_pts, 256), n), dim3(256), 0, b->stream, b->prep_dev);
     PCP_CHECK(hipGetLastError());
     hipLaunchKernelGGL(k_ring_stats_batch, dim3(max_scans, n), dim3(64), 0, b->stream, b->prep_dev);
@@ -1115,22 +1126,33 @@ int pcp_batch_icp_launch(pcp_batch* b, int mode, int max_iter, float tol, int fu
         return pcp_fail("max_iter = %d outside [0, %d]", max_iter, pcp_ctx::max_iter_cap);
     const int n = (int)b->ctxs.size();
     int max_nb = 0, max_scans = 0;
-    // the pinned mirrors may still be read by the previous launch's copy
-    PCP_CHECK(hipStreamSynchronize(b->stream));
+    std::vector<LsArgs> want_ls((size_t)n);
+    std::vector<FinishArgs> want_fin((size_t)n);
     for (int i = 0; i < n; ++i) {
         pcp_ctx* c = b->ctxs[i];
         if (!c->have_target) return pcp_fail("pair %d: no target", i);
         if (c->n_b < 1) return pcp_fail("pair %d: no source", i);
         if (int e = check_ls(c, mode, 0)) return e;
-        b->ls_host[i] = ls_args(c, 0, nullptr);
-        b->fin_host[i] = finish_args(c);
+        memset(&want_ls[i], 0, sizeof(LsArgs));
+        memset(&want_fin[i], 0, sizeof(FinishArgs));
+        want_ls[i] = ls_args(c, 0, nullptr);
+        want_fin[i] = finish_args(c);
         max_nb = c->n_b > max_nb ? c->n_b : max_nb;
         max_scans = c->n_scans > max_scans ? c->n_scans : max_scans;
         c->run_mode = mode;
         c->run_max_iter = max_iter;
     }
-    PCP_CHECK(hipMemcpyAsync(b->ls_dev, b->ls_host, (size_t)n * sizeof(LsArgs), hipMemcpyHostToDevice, b->stream));
-    PCP_CHECK(hipMemcpyAsync(b->fin_dev, b->fin_host, (size_t)n * sizeof(FinishArgs), hipMemcpyHostToDevice, b->stream));
+    if (b->ls_sent.size() != want_ls.size() ||
+        memcmp(b->ls_sent.data(), want_ls.data(), want_ls.size() * sizeof(LsArgs)) != 0 ||
+        memcmp(b->fin_sent.data(), want_fin.data(), want_fin.size() * sizeof(FinishArgs)) != 0) {
+        PCP_CHECK(hipStreamSynchronize(b->stream));      // the pinned mirrors may still be in flight
+        memcpy(b->ls_host, want_ls.data(), want_ls.size() * sizeof(LsArgs));
+        memcpy(b->fin_host, want_fin.data(), want_fin.size() * sizeof(FinishArgs));
+        PCP_CHECK(hipMemcpyAsync(b->ls_dev, b->ls_host, (size_t)n * sizeof(LsArgs), hipMemcpyHostToDevice, b->stream));
+        PCP_CHECK(hipMemcpyAsync(b->fin_dev, b->fin_host, (size_t)n * sizeof(FinishArgs), hipMemcpyHostToDevice, b->stream));
+        b->ls_sent = want_ls;
+        b->fin_sent = want_fin;
+    }
     hipLaunchKernelGGL(k_state_batch, dim3(cdiv(n, 64)), dim3(64), 0, b->stream, b->ls_dev, n, 1);
     PCP_CHECK(hipGetLastError());
     if (max_iter == 0)
