@@ -85,12 +85,19 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # one process per GPU; PCP_BENCH_BACKEND=gloo rehearses the multi-rank path on a box with
+    # fewer GPUs than ranks (ranks then share devices round robin)
+    backend = os.environ.get("PCP_BENCH_BACKEND", "nccl")
+    device = local_rank % max(1, torch.cuda.device_count())
+    torch.cuda.set_device(device)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    torch.cuda.set_device(local_rank)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device))
+        else:
+            dist.init_process_group(backend)
+    local_rank = device
 
     def barrier():
         batch.synchronize()
@@ -121,7 +128,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
