@@ -1,0 +1,81 @@
+"""Full-size cases (BASELINE configs[2]: a 1M-point synthetic sweep): parity with the CPU
+restatement on a sample of the queries, and size-independent properties on all of them
+(hint-guided second pass reproduces the first, voxelization is idempotent and conserves
+points, the table stays sorted)."""
+import numpy as np
+import pytest
+
+from oracle import np_oracle as O
+from oracle import np_voxel as V
+from pointcloudprocessing_amd import ComputeShader, PointcloudIcpContainer, Voxelizer, lidar
+from tests._data import bits
+
+pytestmark = pytest.mark.gpu
+ORIGIN = np.zeros(3)
+
+
+@pytest.fixture(scope="module")
+def big():
+    cloud = lidar.synthetic_scan(3, rings=65, steps=19000)          # ~1.0M points, 64 closed rings
+    cs = ComputeShader(maxPointsPerCloud=len(cloud) + 1000, maxScans=100)
+    yield cloud, cs
+    cs.cleanup()
+
+
+def test_million_point_nn_scan(big):
+    a, cs = big
+    assert 950_000 < len(a) < 1_150_000
+    rng = np.random.default_rng(0)
+    b = a + rng.normal(0.0, 0.02, a.shape)
+    icp = PointcloudIcpContainer(cs)
+    icp.prepareNNS(a, ORIGIN, b)
+    idx, dist = icp.dispatchNNS(b)
+    hint1 = cs.corr_out[:, 3].copy()
+    # parity with the restatement on every 400th query (each query is independent of the others)
+    sel = np.arange(0, len(b), 400)
+    lines = O.get_scan_lines(a, ORIGIN)
+    assert len(lines) == 64
+    st = O.RingIcp(100)
+    st.prepare_nns(a, lines, ORIGIN)
+    ridx, rdist = st.dispatch_nns(b[sel])
+    assert np.array_equal(idx[sel], ridx) and np.array_equal(bits(dist[sel]), bits(rdist))
+    assert np.array_equal(bits(hint1[sel]), bits(st.hint))
+    # properties on all queries: the perturbed point's own original is a candidate, so the
+    # match is never further than that; a second, hint-guided pass changes nothing
+    own = ((O.pad_points(b) - O.pad_points(a)) ** 2).sum(1)
+    ringed = np.zeros(len(a), bool)
+    for s, e in lines:
+        ringed[s:e + 1] = True
+    assert np.mean(dist[ringed] <= own[ringed] * 1.0001 + 1e-9) > 0.98
+    idx2, dist2 = icp.dispatchNNS(b)
+    assert np.array_equal(idx, idx2) and np.array_equal(bits(dist), bits(dist2))
+    assert np.array_equal(bits(hint1), bits(cs.corr_out[:, 3]))
+
+
+@pytest.mark.parametrize("voxel_size", [0.1, 0.5, 2.0])
+def test_million_point_voxelize(big, voxel_size):
+    a, cs = big
+    v = Voxelizer(cs, None)
+    v.init(voxel_size)
+    v.filter_outliers = True
+    v.addPoints(a, None)
+    m = V.VoxelMap(voxel_size)
+    m.add_points(a)
+    s = v.stored_voxels
+    assert s == m.stored and np.array_equal(v.voxel_index[:s], m.voxel_index[:s])
+    assert np.array_equal(v.voxel_data[:s, 0], m.voxel_data[:s, 0]) and v.voxel_data[:s, 0].sum() == len(a)
+    keys = V._keys(v.voxel_index[:s, :3])
+    assert np.all(np.diff(keys) > 0)                                   # sorted, no duplicate voxel
+    # idempotence: the same cloud again finds every voxel, appends on the device, creates nothing
+    before = v.voxel_data[:s, 0].copy()
+    v.addPoints(a, None)
+    assert v.stored_voxels == s
+    v.refreshVoxelData()
+    assert np.array_equal(v.voxel_data[:s, 0], 2 * before)
+    small = v.voxel_data[:s, 0] < v.max_points
+    rows = np.nonzero(small)[0][:: max(1, small.sum() // 500)]
+    coords = v.vectorizedGetVoxelCoord(v.added_points[:v.last_added_point, :3])
+    for r in rows:
+        ids = v.voxel_data[r, 1:v.voxel_data[r, 0] + 1]
+        pos = np.nonzero(v.voxel_index[:s, 3] == r)[0][0]
+        assert len(np.unique(ids)) == len(ids) and np.all(coords[ids] == v.voxel_index[pos, :3])
