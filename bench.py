@@ -167,6 +167,16 @@ def main():
     avg_launch_s = ls_ms * 1e-3 / max(ls_launches, 1)
     achieved = alg_bytes / avg_launch_s / 1e9
 
+    # HBM traffic per launch of that kernel comes from counter passes that cannot run inside this
+    # process (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, one pass each); their committed summary is
+    # quoted when it was taken on this very workload, else traffic stays null
+    traffic = None
+    import glob
+    for tf in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))[-1:]:
+        tr = json.load(open(tf))
+        if (tr.get("pairs_per_launch"), tr.get("n_a"), tr.get("n_b")) == (args.pairs, n_a, n_b):
+            traffic = tr["fetch_bytes_per_launch"] + tr["write_bytes_per_launch"]
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import np_oracle as O
@@ -200,7 +210,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "k_ls_batch<plane> (fused ring-NN + JtJ/Jte + level-1 tree sum, "
                                                    "all pairs of the step in one launch)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "avg_launch_us": avg_launch_s * 1e6, "launches_timed": ls_launches,
                          "algorithmic_bytes_per_launch": alg_bytes},
             "cpu_baseline": cpu,
