@@ -21,6 +21,7 @@
 #ifndef PCP_H
 #define PCP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -192,6 +193,84 @@ int pcp_profile_read(pcp_ctx* ctx, float* ls_ms, int* launches);
  * with HIP events recorded on that stream. */
 int pcp_timer_start(pcp_ctx* ctx);
 int pcp_timer_stop(pcp_ctx* ctx, float* ms);
+
+/* ---------------------------------------------------------------------------
+ * Exact nearest neighbours on a cell grid (ring-less clouds, maps).
+ * Stands in for the reference's scipy KD-tree: PointcloudIcpContainer.getKDTree
+ * (:471-472), getNearestNeighbours (:467-469), icp_step_KD (:474-498) and
+ * align_KD (:500-515).  Points are float64 rows of 3 (x, y, z), as the KD-tree
+ * receives them.  One pcp_grid per device and map; calls on one grid must be
+ * serialised by the caller.
+ * ------------------------------------------------------------------------- */
+typedef struct pcp_grid pcp_grid;
+
+int pcp_grid_create(int device, pcp_grid** out);
+int pcp_grid_destroy(pcp_grid* grid);
+int pcp_grid_set_stream(pcp_grid* grid, void* hip_stream);
+int pcp_grid_synchronize(pcp_grid* grid);
+/* getKDTree (:471-472): index n map points with cubic cells of edge `cell`
+ * (Morton-sorted, hash of occupied cells).  normals_xyzw (n rows of 4 float32, or
+ * NULL) are carried along for the plane mode of pcp_grid_ls*. */
+int pcp_grid_build(pcp_grid* grid, const double* xyz, size_t n, double cell, const float* normals_xyzw);
+/* Facts about the last build: points, occupied cells, extent in cells, radix
+ * passes, device time of the whole build and of the sort alone (ms). Any pointer may be NULL. */
+int pcp_grid_info(pcp_grid* grid, unsigned long long* n_points, unsigned long long* n_cells, int* extent3,
+                  int* sort_passes, float* build_ms, float* sort_ms);
+/* The map in its sorted order: original index and coordinates of every entry. */
+int pcp_grid_sorted_ids(pcp_grid* grid, long long* ids, double* xyz);
+/* Upload m source points as the resident working copy (and a pristine copy that
+ * pcp_grid_source_rewind restores). */
+int pcp_grid_source(pcp_grid* grid, const double* xyz, size_t m);
+int pcp_grid_source_rewind(pcp_grid* grid);
+int pcp_grid_source_read(pcp_grid* grid, double* xyz);
+/* applyIcpStep (:315-317): p <- R p + t on the working copy; minus_t != 0 gives
+ * apply_iteration_of_ls (:172-174): p <- R p - t. */
+int pcp_grid_source_apply(pcp_grid* grid, const double* R9, const double* t3, int minus_t);
+/* KDTree.query (:468): exact nearest map point of every source point: idx = its
+ * index in the array given to pcp_grid_build (-1 if none), dist = Euclidean
+ * distance (+inf if none).  max_dist <= 0 or inf searches without bound, else
+ * only points strictly nearer than max_dist count (distance_upper_bound).
+ * Ties go to the lowest index.  kernel_ms (or NULL) receives the kernel's time. */
+int pcp_grid_query_resident(pcp_grid* grid, double max_dist, long long* idx, double* dist, float* kernel_ms);
+/* pcp_grid_source + pcp_grid_query_resident. */
+int pcp_grid_query(pcp_grid* grid, const double* q_xyz, size_t m, double max_dist, long long* idx, double* dist);
+/* icp_step_KD (:474-498) up to the SVD: nearest neighbours of the working copy,
+ * the int(m * keep_fraction) pairs with the smallest distances (ties at the cut
+ * by source index), their means and W = sum (ref - mean_ref)(other - mean_other)^T
+ * (row-major 3x3, ref = map point).  The caller finishes with U, S, Vh = svd(W),
+ * R = U Vh, t = mean_ref - R mean_other. */
+int pcp_grid_kd_step(pcp_grid* grid, double keep_fraction, double* mean_ref3, double* mean_other3, double* W9,
+                     unsigned long long* taken);
+/* Per-point results of the last query / kd step / pcp_grid_ls: index, distance,
+ * membership of the trimmed set (kd step only).  Any pointer may be NULL. */
+int pcp_grid_nn_read(pcp_grid* grid, long long* idx, double* dist, unsigned char* selected);
+
+/* Scan-to-map least squares.  The tile arithmetic is LeastSquaresPoint.glsl /
+ * LeastSquaresPlane.glsl (thresholds 0.1 / 0.2 on the float32 squared distance)
+ * and the ParalellHBSum tree over the source points in order, with the exact
+ * neighbour within `radius` in place of the ring search; a source point without
+ * such a neighbour contributes zeros.  No counterpart in the reference, which
+ * registers scans against single frames only.
+ * pcp_grid_ls: one dispatch on the working copy, H|b as dispatchLS returns them (8x8). */
+int pcp_grid_ls(pcp_grid* grid, int mode, double radius, float* hb);
+/* Device-resident loop on one GPU (the map analogue of pcp_icp_run): starts from
+ * the working copy, leaves the registered cloud there. */
+int pcp_grid_icp_run(pcp_grid* grid, int mode, double radius, int max_iter, float tol, int full_iter,
+                     float* dx_trace, float* hb_trace, int* iters, int* converged);
+/* The same loop cut at its one exchange point, for a map split over ranks: each rank
+ * holds the map points in or next to its share of the cell-key space and sums only
+ * the source points whose cell key k satisfies lo <= k < hi (keys: pcp_grid_cell_keys);
+ * the partial 8x8 tiles are all-reduced by the caller between the two calls and every
+ * rank solves the same system.  Both calls only enqueue work on the grid's stream;
+ * tile_dev is a device buffer of 64 floats. */
+int pcp_grid_set_owned_keys(pcp_grid* grid, unsigned long long lo, unsigned long long hi);
+int pcp_grid_cell_keys(double cell, const double* xyz, size_t n, unsigned long long* keys);
+int pcp_grid_icp_reset(pcp_grid* grid);
+int pcp_grid_ls_dev(pcp_grid* grid, int mode, double radius, float* tile_dev);
+int pcp_grid_pose_dev(pcp_grid* grid, const float* tile_dev, int mode, int max_iter, float tol, int full_iter);
+/* Applies the step still pending after the last pcp_grid_pose_dev. */
+int pcp_grid_icp_finish(pcp_grid* grid);
+int pcp_grid_icp_fetch(pcp_grid* grid, float* dx_trace, float* hb_trace, int* iters, int* converged, int* done);
 
 #ifdef __cplusplus
 }

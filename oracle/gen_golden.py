@@ -8,6 +8,7 @@ Needs /root/reference (read-only).  Three kinds of vectors:
                    (PointcloudIcpContainer, PointcloudAlignment), the known
                    answers that pin the restatement in oracle/np_oracle.py
   ref_voxel.npz    the reference's own Voxelizer (CPU path) on the two KITTI frames
+  ref_kd.npz       the reference's legacy KD-tree ICP (icp_step_KD, align_KD) on the pair
   oracle_kitti.npz outputs of oracle/np_oracle.py on the KITTI pair (full-size
                    parity targets for the HIP kernels, so GPU tests need not
                    rerun the slow NumPy search)
@@ -147,6 +148,23 @@ def ref_voxel(frames):
     np.savez_compressed(os.path.join(OUT, "ref_voxel.npz"), **out)
 
 
+def ref_kd(frames):
+    """The reference's legacy exact-neighbour ICP (PointcloudIcpContainer.icp_step_KD / align_KD,
+    :474-515) on the KITTI pair, and its KD-tree neighbours of every 7th point."""
+    sys.path.insert(0, REF)
+    from PointcloudIcpContainer import PointcloudIcpContainer
+    icp = PointcloudIcpContainer(None, None)
+    out = {}
+    tree = icp.getKDTree(frames[0])
+    dd, ii = tree.query(frames[1][::7])
+    out.update(kd7_idx=ii.astype(np.int32), kd7_dist=dd)
+    R, t = icp.icp_step_KD(tree, frames[0], frames[1])
+    out.update(step_R=R, step_t=t)
+    moved, R_opt, t_opt = icp.align_KD(frames[0], frames[1])
+    out.update(align_R=R_opt, align_t=t_opt, align_moved_sub=moved[::64].copy())
+    np.savez_compressed(os.path.join(OUT, "ref_kd.npz"), **out)
+
+
 def oracle_kitti(frames):
     from oracle import np_oracle as O
     A, B = frames
@@ -183,6 +201,8 @@ if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     raw = kitti_pair()
     frames = ref_kat(raw)
+    if "--no-kd" not in sys.argv:
+        ref_kd(frames)
     if "--no-voxel" not in sys.argv:
         ref_voxel(frames)
     if "--no-oracle" not in sys.argv:

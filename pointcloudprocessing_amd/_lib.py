@@ -56,6 +56,30 @@ SIGNATURES = {
     "pcp_voxel_data_read": (C.c_int, [_ctx, C.c_int, C.c_int, _i32p]),
     "pcp_voxelize": (C.c_int, [_ctx, _f32p, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, _i32p, C.c_int, _f32p]),
     "pcp_voxel_stage": (C.c_int, [_ctx, _f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _i32p, _i32p]),
+    "pcp_grid_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
+    "pcp_grid_destroy": (C.c_int, [C.c_void_p]),
+    "pcp_grid_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "pcp_grid_synchronize": (C.c_int, [C.c_void_p]),
+    "pcp_grid_build": (C.c_int, [C.c_void_p, _f64p, C.c_size_t, C.c_double, _f32p]),
+    "pcp_grid_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong), _i32p, _i32p, _f32p, _f32p]),
+    "pcp_grid_sorted_ids": (C.c_int, [C.c_void_p, C.POINTER(C.c_longlong), _f64p]),
+    "pcp_grid_source": (C.c_int, [C.c_void_p, _f64p, C.c_size_t]),
+    "pcp_grid_source_rewind": (C.c_int, [C.c_void_p]),
+    "pcp_grid_source_read": (C.c_int, [C.c_void_p, _f64p]),
+    "pcp_grid_source_apply": (C.c_int, [C.c_void_p, _f64p, _f64p, C.c_int]),
+    "pcp_grid_query_resident": (C.c_int, [C.c_void_p, C.c_double, C.POINTER(C.c_longlong), _f64p, _f32p]),
+    "pcp_grid_query": (C.c_int, [C.c_void_p, _f64p, C.c_size_t, C.c_double, C.POINTER(C.c_longlong), _f64p]),
+    "pcp_grid_kd_step": (C.c_int, [C.c_void_p, C.c_double, _f64p, _f64p, _f64p, C.POINTER(C.c_ulonglong)]),
+    "pcp_grid_nn_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_longlong), _f64p, C.POINTER(C.c_ubyte)]),
+    "pcp_grid_ls": (C.c_int, [C.c_void_p, C.c_int, C.c_double, _f32p]),
+    "pcp_grid_icp_run": (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_float, C.c_int, _f32p, _f32p, _i32p, _i32p]),
+    "pcp_grid_set_owned_keys": (C.c_int, [C.c_void_p, C.c_ulonglong, C.c_ulonglong]),
+    "pcp_grid_cell_keys": (C.c_int, [C.c_double, _f64p, C.c_size_t, C.POINTER(C.c_ulonglong)]),
+    "pcp_grid_icp_reset": (C.c_int, [C.c_void_p]),
+    "pcp_grid_ls_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_void_p]),
+    "pcp_grid_pose_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_int]),
+    "pcp_grid_icp_finish": (C.c_int, [C.c_void_p]),
+    "pcp_grid_icp_fetch": (C.c_int, [C.c_void_p, _f32p, _f32p, _i32p, _i32p, _i32p]),
     "pcp_batch_create": (C.c_int, [C.POINTER(_ctx), C.c_int, C.POINTER(C.c_void_p)]),
     "pcp_batch_destroy": (C.c_int, [C.c_void_p]),
     "pcp_batch_prepare": (C.c_int, [C.c_void_p, C.c_int]),

@@ -1,0 +1,156 @@
+"""Exact nearest neighbours on the GPU for ring-less clouds and maps.
+
+`CellGrid` stands where the reference builds a scipy KD-tree
+(PointcloudIcpContainer.getKDTree, PointcloudIcpContainer.py:471-472): it is
+constructed from the target points and answers `query(points)` with the same
+(distances, indices) pair (:468).  The target is binned into cubic cells on the
+device (Morton sort + hash of occupied cells, pcp_grid_build); every query is
+exact in float64, ties go to the lowest index.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import check, f32p, f64p
+
+MODE_POINT, MODE_PLANE = 0, 1
+
+
+def _i64p(a):
+    return None if a is None else a.ctypes.data_as(C.POINTER(C.c_longlong))
+
+
+def auto_cell(points):
+    """Cell edge that puts a handful of points into an occupied cell of a surface-like cloud."""
+    p = np.asarray(points, dtype=np.float64)
+    if len(p) < 2:
+        return 1.0
+    ext = np.maximum(p.max(axis=0) - p.min(axis=0), 1e-9)
+    return float(max((np.prod(ext) / len(p)) ** (1.0 / 3.0), float(ext.max()) * 2.0 ** -19))
+
+
+class CellGrid:
+    def __init__(self, np_points, cell=None, normals=None, device=0):
+        self._lib = _lib.load()
+        self._g = C.c_void_p()
+        check(self._lib.pcp_grid_create(int(device), C.byref(self._g)))
+        self.device = int(device)
+        self.rebuild(np_points, cell, normals)
+
+    def rebuild(self, np_points, cell=None, normals=None):
+        pts = np.ascontiguousarray(np.asarray(np_points, dtype=np.float64)[:, :3])
+        self.data = pts                                   # scipy's KDTree.data
+        self.n = len(pts)
+        self.cell = float(cell) if cell is not None else auto_cell(pts)
+        nrm = None
+        if normals is not None:
+            nrm = np.zeros((len(pts), 4), dtype=np.float32)
+            nn = np.asarray(normals, dtype=np.float32)
+            nrm[:, :nn.shape[1]] = nn
+        check(self._lib.pcp_grid_build(self._g, f64p(pts), len(pts), self.cell, f32p(nrm)))
+        self.m = 0
+
+    def info(self):
+        n, cells = C.c_ulonglong(0), C.c_ulonglong(0)
+        ext = np.zeros(3, dtype=np.int32)
+        passes, bms, sms = C.c_int(0), C.c_float(0), C.c_float(0)
+        check(self._lib.pcp_grid_info(self._g, C.byref(n), C.byref(cells), _lib.i32p(ext), C.byref(passes),
+                                      C.byref(bms), C.byref(sms)))
+        return {"points": n.value, "cells": cells.value, "extent": ext.tolist(), "cell": self.cell,
+                "sort_passes": passes.value, "build_ms": bms.value, "sort_ms": sms.value}
+
+    def sorted_points(self):
+        ids = np.zeros(self.n, dtype=np.int64)
+        xyz = np.zeros((self.n, 3), dtype=np.float64)
+        check(self._lib.pcp_grid_sorted_ids(self._g, _i64p(ids), f64p(xyz)))
+        return ids, xyz
+
+    # -- source cloud ---------------------------------------------------------------------
+    def set_source(self, np_points):
+        src = np.ascontiguousarray(np.asarray(np_points, dtype=np.float64)[:, :3])
+        check(self._lib.pcp_grid_source(self._g, f64p(src), len(src)))
+        self.m = len(src)
+
+    def rewind_source(self):
+        check(self._lib.pcp_grid_source_rewind(self._g))
+
+    def read_source(self):
+        out = np.zeros((self.m, 3), dtype=np.float64)
+        check(self._lib.pcp_grid_source_read(self._g, f64p(out)))
+        return out
+
+    def apply(self, R, t, minus_t=False):
+        R = np.ascontiguousarray(R, dtype=np.float64)
+        t = np.ascontiguousarray(t, dtype=np.float64)
+        check(self._lib.pcp_grid_source_apply(self._g, f64p(R), f64p(t), 1 if minus_t else 0))
+
+    # -- KDTree.query ---------------------------------------------------------------------
+    def query(self, np_points=None, distance_upper_bound=np.inf, return_kernel_ms=False):
+        """(distances, indices) of the nearest target point of every row, as scipy's KDTree.query
+        with k=1; misses under a finite bound give (inf, n) like scipy.  Without points the
+        resident source cloud is queried."""
+        if np_points is not None:
+            self.set_source(np_points)
+        idx = np.zeros(self.m, dtype=np.int64)
+        dist = np.zeros(self.m, dtype=np.float64)
+        ms = C.c_float(0)
+        bound = float(distance_upper_bound) if np.isfinite(distance_upper_bound) else 0.0
+        check(self._lib.pcp_grid_query_resident(self._g, bound, _i64p(idx), f64p(dist), C.byref(ms)))
+        idx[idx < 0] = self.n
+        return (dist, idx, ms.value) if return_kernel_ms else (dist, idx)
+
+    def nn_results(self, selected=False):
+        idx = np.zeros(self.m, dtype=np.int64)
+        dist = np.zeros(self.m, dtype=np.float64)
+        sel = np.zeros(self.m, dtype=np.uint8) if selected else None
+        check(self._lib.pcp_grid_nn_read(self._g, _i64p(idx), f64p(dist),
+                                         None if sel is None else sel.ctypes.data_as(C.POINTER(C.c_ubyte))))
+        return (idx, dist, sel.astype(bool)) if selected else (idx, dist)
+
+    # -- icp_step_KD ----------------------------------------------------------------------
+    def kd_step(self, keep_fraction=0.8):
+        """icp_step_KD (PointcloudIcpContainer.py:474-498) on the resident source: returns (R, t)."""
+        mr, mo, W = np.zeros(3), np.zeros(3), np.zeros((3, 3))
+        taken = C.c_ulonglong(0)
+        check(self._lib.pcp_grid_kd_step(self._g, float(keep_fraction), f64p(mr), f64p(mo), f64p(W), C.byref(taken)))
+        U, S, Vh = np.linalg.svd(W)
+        R = U @ Vh
+        t = mr - R @ mo
+        return R, t
+
+    # -- scan-to-map least squares ----------------------------------------------------------
+    def ls(self, mode, radius):
+        hb = np.zeros((8, 8), dtype=np.float32)
+        check(self._lib.pcp_grid_ls(self._g, int(mode), float(radius), f32p(hb)))
+        return hb[:6, :6].copy(), hb[:6, 6].copy()
+
+    def icp_run(self, mode, radius, max_iter=10, tol=1e-6, full_iter=False):
+        dx = np.zeros((max_iter, 6), dtype=np.float32)
+        hb = np.zeros((max_iter, 8, 8), dtype=np.float32)
+        it, cv = C.c_int(0), C.c_int(0)
+        check(self._lib.pcp_grid_icp_run(self._g, int(mode), float(radius), int(max_iter), float(tol),
+                                         1 if full_iter else 0, f32p(dx), f32p(hb), C.byref(it), C.byref(cv)))
+        return dx[:it.value], bool(cv.value), hb[:it.value]
+
+    def set_owned_keys(self, lo, hi):
+        check(self._lib.pcp_grid_set_owned_keys(self._g, int(lo), int(hi)))
+
+    def cleanup(self):
+        if self._g:
+            check(self._lib.pcp_grid_destroy(self._g))
+            self._g = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.cleanup()
+        except Exception:
+            pass
+
+
+def cell_keys(points, cell):
+    """Absolute Morton key of the cell of every point (the key space ranks split)."""
+    p = np.ascontiguousarray(np.asarray(points, dtype=np.float64)[:, :3])
+    keys = np.zeros(len(p), dtype=np.uint64)
+    check(_lib.load().pcp_grid_cell_keys(float(cell), f64p(p), len(p), keys.ctypes.data_as(C.POINTER(C.c_ulonglong))))
+    return keys

@@ -1,0 +1,1193 @@
+// Exact nearest neighbours for ring-less clouds and maps, and the registration
+// steps built on them.
+//
+// The reference's exact search is a scipy KD-tree on float64 points
+// (PointcloudIcpContainer.getKDTree / getNearestNeighbours, :467-472) feeding the
+// trimmed Kabsch step icp_step_KD (:474-498).  Here the target ("map") is binned
+// into cubic cells, sorted by the Morton code of its cell with a hand-written LSD
+// radix sort, and indexed by an open-addressing hash table of the occupied cells.
+// A query walks the cell shells around its own cell outwards until the best
+// distance found is smaller than the distance to the unvisited space, so the
+// answer is the exact float64 minimum (lowest point index on ties), as the
+// KD-tree's.
+//
+// Device buffers (all float64 unless noted):
+//   pts      {x, y, z, id} per map point, sorted by cell key            32 B / point
+//   normals  float4 per map point in the same order (optional)          16 B / point
+//   table    {key, start, count} per hash slot, capacity >= 2 x cells   16 B / slot
+//   src_in / src   source cloud as uploaded (for rewinding) / working copy  24 B / point
+//   nn_d, nn_idx, nn_pos, sel    per source point: distance, map point id,
+//                                position in pts, membership of the trimmed set
+//   partials, lvl0, lvl1, state, hb_trace, dx_trace: as in the ring registration.
+#include <hip/hip_runtime.h>
+#include <limits.h>
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+
+#include <cmath>
+
+#include <algorithm>
+#include <vector>
+
+#include "../../include/pcp.h"
+#include "pcp_ctx.h"
+#include "pcp_device.h"
+#include "pcp_host.h"
+#include "pcp_solve.h"
+
+using namespace pcp;
+
+namespace {
+
+struct __align__(32) GridPoint { double x, y, z; long long id; };
+struct __align__(16) Cell { unsigned long long key; unsigned int start, count; };
+constexpr unsigned long long EMPTY_KEY = 0xFFFFFFFFFFFFFFFFull;
+constexpr int COORD_BIAS = 1 << 20;          // absolute cell coordinates live in [-2^20, 2^20)
+constexpr int COORD_CLAMP = 1 << 29;
+
+struct GridView {
+    const GridPoint* pts;
+    const Cell* table;
+    int log_cap;
+    size_t n;
+    double cell, eps;
+    int cminx, cminy, cminz;     // absolute cell coordinates of the grid's corner
+    int ex, ey, ez;              // grid extent in cells
+};
+
+__host__ __device__ inline unsigned long long spread21(unsigned long long v) {
+    v &= 0x1FFFFFull;
+    v = (v | (v << 32)) & 0x1F00000000FFFFull;
+    v = (v | (v << 16)) & 0x1F0000FF0000FFull;
+    v = (v | (v << 8)) & 0x100F00F00F00F00Full;
+    v = (v | (v << 4)) & 0x10C30C30C30C30C3ull;
+    v = (v | (v << 2)) & 0x1249249249249249ull;
+    return v;
+}
+__host__ __device__ inline unsigned long long morton3(unsigned x, unsigned y, unsigned z) {
+    return spread21(x) | (spread21(y) << 1) | (spread21(z) << 2);
+}
+
+__device__ __forceinline__ int cell_of(const double v, const double cell) {
+    double f = floor(v / cell);
+    f = fmin(fmax(f, -(double)COORD_CLAMP), (double)COORD_CLAMP);
+    return (f == f) ? (int)f : COORD_CLAMP;
+}
+
+__device__ __forceinline__ unsigned hash_slot(const unsigned long long key, const int log_cap) {
+    return (unsigned)((key * 0x9E3779B97F4A7C15ull) >> (64 - log_cap));
+}
+
+// ------------------------------------------------------------------------------------------
+// build: cell range, keys, radix sort, hash table, gather
+// ------------------------------------------------------------------------------------------
+
+__global__ void k_cell_range(const double* __restrict__ xyz, size_t n, double cell, int* __restrict__ mm) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int lo[3] = {INT_MAX, INT_MAX, INT_MAX}, hi[3] = {INT_MIN, INT_MIN, INT_MIN};
+    int bad = 0;
+    if (i < n) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const double v = xyz[3 * i + a];
+            if (!(fabs(v / cell) < (double)(COORD_BIAS - 2))) bad = 1;
+            lo[a] = hi[a] = cell_of(v, cell);
+        }
+    }
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            lo[a] = min(lo[a], __shfl_down(lo[a], s, 64));
+            hi[a] = max(hi[a], __shfl_down(hi[a], s, 64));
+        }
+        bad |= __shfl_down(bad, s, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            atomicMin(&mm[a], lo[a]);
+            atomicMax(&mm[3 + a], hi[a]);
+        }
+        if (bad) atomicOr(&mm[6], 1);
+    }
+}
+
+__global__ void k_cell_keys(const double* __restrict__ xyz, size_t n, double cell, int cx, int cy, int cz,
+                            unsigned long long* __restrict__ keys, unsigned* __restrict__ vals) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const unsigned x = (unsigned)(cell_of(xyz[3 * i + 0], cell) - cx);
+    const unsigned y = (unsigned)(cell_of(xyz[3 * i + 1], cell) - cy);
+    const unsigned z = (unsigned)(cell_of(xyz[3 * i + 2], cell) - cz);
+    keys[i] = morton3(x, y, z);
+    vals[i] = (unsigned)i;
+}
+
+// LSD radix sort, 8 bits per pass, stable.  A block owns a tile of 2048 keys.
+constexpr int RS_THREADS = 256;
+constexpr int RS_TILE = 2048;
+
+__global__ void __launch_bounds__(RS_THREADS)
+k_rs_hist(const unsigned long long* __restrict__ keys, size_t n, int shift, unsigned* __restrict__ hist, int nblk) {
+    __shared__ unsigned h[256];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const size_t base = (size_t)blockIdx.x * RS_TILE;
+#pragma unroll
+    for (int i = 0; i < RS_TILE / RS_THREADS; ++i) {
+        const size_t j = base + (size_t)i * RS_THREADS + threadIdx.x;
+        if (j < n) atomicAdd(&h[(unsigned)(keys[j] >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    hist[(size_t)threadIdx.x * nblk + blockIdx.x] = h[threadIdx.x];     // digit-major
+}
+
+// Block d: exclusive prefix of hist[d][0..nblk) in place, digit total to totals[d].
+__global__ void __launch_bounds__(256) k_rs_scan(unsigned* __restrict__ hist, int nblk, unsigned* __restrict__ totals) {
+    __shared__ unsigned s[256];
+    unsigned* h = hist + (size_t)blockIdx.x * nblk;
+    unsigned run = 0;
+    for (int base = 0; base < nblk; base += 256) {
+        const int i = base + threadIdx.x;
+        const unsigned v = (i < nblk) ? h[i] : 0u;
+        s[threadIdx.x] = v;
+        __syncthreads();
+        for (int off = 1; off < 256; off <<= 1) {
+            const unsigned t = (threadIdx.x >= (unsigned)off) ? s[threadIdx.x - off] : 0u;
+            __syncthreads();
+            s[threadIdx.x] += t;
+            __syncthreads();
+        }
+        if (i < nblk) h[i] = run + s[threadIdx.x] - v;
+        run += s[255];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) totals[blockIdx.x] = run;
+}
+
+__global__ void __launch_bounds__(256) k_rs_base(const unsigned* __restrict__ totals, unsigned* __restrict__ base) {
+    __shared__ unsigned s[256];
+    const unsigned v = totals[threadIdx.x];
+    s[threadIdx.x] = v;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {
+        const unsigned t = (threadIdx.x >= (unsigned)off) ? s[threadIdx.x - off] : 0u;
+        __syncthreads();
+        s[threadIdx.x] += t;
+        __syncthreads();
+    }
+    base[threadIdx.x] = s[threadIdx.x] - v;
+}
+
+// Each wave ranks its own 512 consecutive keys (8 rounds of 64, in order), so
+// the rank of a key among equal digits is: digit base + blocks before + waves
+// before + earlier rounds of this wave + lower lanes of this round.
+__global__ void __launch_bounds__(RS_THREADS)
+k_rs_scatter(const unsigned long long* __restrict__ keys_in, const unsigned* __restrict__ vals_in, size_t n, int shift,
+             const unsigned* __restrict__ hist, const unsigned* __restrict__ base, int nblk,
+             unsigned long long* __restrict__ keys_out, unsigned* __restrict__ vals_out) {
+    __shared__ unsigned cnt[4][256];
+    __shared__ unsigned goff[256];
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+    for (int j = tid; j < 4 * 256; j += RS_THREADS) (&cnt[0][0])[j] = 0;
+    goff[tid] = base[tid] + hist[(size_t)tid * nblk + blockIdx.x];
+    __syncthreads();
+    unsigned long long k[8];
+    unsigned v[8], loc[8];
+    const size_t seg = (size_t)blockIdx.x * RS_TILE + (size_t)w * 512;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const size_t j = seg + (size_t)i * 64 + lane;
+        const bool valid = j < n;
+        k[i] = valid ? keys_in[j] : EMPTY_KEY;
+        v[i] = valid ? vals_in[j] : 0u;
+        const unsigned digit = (unsigned)(k[i] >> shift) & 255u;
+        unsigned long long mask = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const bool bit = (digit >> b) & 1u;
+            const unsigned long long bm = __ballot(valid && bit);
+            mask &= bit ? bm : ~bm;
+        }
+        int leader = lane;
+        unsigned rank = 0, old = 0;
+        if (valid) {
+            rank = (unsigned)__popcll(mask & ((1ull << lane) - 1ull));
+            leader = __ffsll((long long)mask) - 1;
+            if (lane == leader) old = atomicAdd(&cnt[w][digit], (unsigned)__popcll(mask));
+        }
+        old = __shfl(old, leader, 64);
+        loc[i] = old + rank;
+    }
+    __syncthreads();
+    {
+        const unsigned c0 = cnt[0][tid], c1 = cnt[1][tid], c2 = cnt[2][tid];
+        cnt[0][tid] = 0;
+        cnt[1][tid] = c0;
+        cnt[2][tid] = c0 + c1;
+        cnt[3][tid] = c0 + c1 + c2;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const size_t j = seg + (size_t)i * 64 + lane;
+        if (j < n) {
+            const unsigned digit = (unsigned)(k[i] >> shift) & 255u;
+            const size_t pos = (size_t)goff[digit] + cnt[w][digit] + loc[i];
+            keys_out[pos] = k[i];
+            vals_out[pos] = v[i];
+        }
+    }
+}
+
+__global__ void k_count_cells(const unsigned long long* __restrict__ keys, size_t n, unsigned long long* __restrict__ count) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool start = i < n && (i == 0 || keys[i] != keys[i - 1]);
+    const unsigned long long m = __ballot(start);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(count, (unsigned long long)__popcll(m));
+}
+
+__global__ void k_insert_cells(const unsigned long long* __restrict__ keys, size_t n, Cell* __restrict__ table, int log_cap) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || (i != 0 && keys[i] == keys[i - 1])) return;
+    const unsigned long long key = keys[i];
+    const unsigned mask = (1u << log_cap) - 1u;
+    unsigned slot = hash_slot(key, log_cap);
+    while (true) {
+        const unsigned long long old = atomicCAS(&table[slot].key, EMPTY_KEY, key);
+        if (old == EMPTY_KEY || old == key) { table[slot].start = (unsigned)i; return; }
+        slot = (slot + 1) & mask;
+    }
+}
+
+__device__ __forceinline__ bool find_cell(const Cell* __restrict__ table, const int log_cap, const unsigned long long key,
+                                          unsigned& start, unsigned& count) {
+    const unsigned mask = (1u << log_cap) - 1u;
+    unsigned slot = hash_slot(key, log_cap);
+    while (true) {
+        const ulonglong2 c = *reinterpret_cast<const ulonglong2*>(&table[slot]);
+        if (c.x == key) { start = (unsigned)c.y; count = (unsigned)(c.y >> 32); return true; }
+        if (c.x == EMPTY_KEY) return false;
+        slot = (slot + 1) & mask;
+    }
+}
+
+__global__ void k_close_cells(const unsigned long long* __restrict__ keys, size_t n, Cell* __restrict__ table, int log_cap) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || (i + 1 != n && keys[i] == keys[i + 1])) return;
+    const unsigned long long key = keys[i];
+    const unsigned mask = (1u << log_cap) - 1u;
+    unsigned slot = hash_slot(key, log_cap);
+    while (table[slot].key != key) slot = (slot + 1) & mask;       // inserted by k_insert_cells
+    table[slot].count = (unsigned)(i + 1) - table[slot].start;
+}
+
+__global__ void k_gather_points(const double* __restrict__ xyz, const unsigned* __restrict__ vals, size_t n,
+                                const float4* __restrict__ normals_in, GridPoint* __restrict__ pts,
+                                float4* __restrict__ normals) {
+    const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const unsigned i = vals[j];
+    GridPoint p;
+    p.x = xyz[3 * (size_t)i + 0]; p.y = xyz[3 * (size_t)i + 1]; p.z = xyz[3 * (size_t)i + 2];
+    p.id = (long long)i;
+    pts[j] = p;
+    if (normals_in) normals[j] = normals_in[i];
+}
+
+// ------------------------------------------------------------------------------------------
+// exact nearest neighbour
+// ------------------------------------------------------------------------------------------
+
+__device__ __forceinline__ double axis_gap(const double q, const double lo, const double hi, const double eps) {
+    const double g = fmax(fmax(lo - q, q - hi), 0.0) - eps;
+    return fmax(g, 0.0);
+}
+
+__device__ __forceinline__ void visit_cell(const GridView& G, const int x, const int y, const int z,
+                                           const double qx, const double qy, const double qz,
+                                           double& best, long long& bid, int& bpos) {
+    // no point of the cell can be nearer than the cell's box
+    const double gx = axis_gap(qx, (double)(x + G.cminx) * G.cell, (double)(x + G.cminx + 1) * G.cell, G.eps);
+    const double gy = axis_gap(qy, (double)(y + G.cminy) * G.cell, (double)(y + G.cminy + 1) * G.cell, G.eps);
+    const double gz = axis_gap(qz, (double)(z + G.cminz) * G.cell, (double)(z + G.cminz + 1) * G.cell, G.eps);
+    if ((gx * gx + gy * gy) + gz * gz > best) return;
+    unsigned start, count;
+    if (!find_cell(G.table, G.log_cap, morton3((unsigned)x, (unsigned)y, (unsigned)z), start, count)) return;
+    for (unsigned j = start; j < start + count; ++j) {
+        const GridPoint p = G.pts[j];
+        const double dx = qx - p.x, dy = qy - p.y, dz = qz - p.z;
+        const double d2 = (dx * dx + dy * dy) + dz * dz;
+        if (d2 < best || (d2 == best && p.id < bid)) { best = d2; bid = p.id; bpos = (int)j; }
+    }
+}
+
+// best must hold the squared search radius (or +inf) on entry; only strictly
+// nearer points are accepted.  bid = -1 when nothing is.
+__device__ __forceinline__ void grid_nn(const GridView& G, const double qx, const double qy, const double qz,
+                                        double& best, long long& bid, int& bpos) {
+    bid = -1;
+    bpos = -1;
+    if (G.n == 0) return;
+    const int ax = cell_of(qx, G.cell), ay = cell_of(qy, G.cell), az = cell_of(qz, G.cell);
+    const int cx = ax - G.cminx, cy = ay - G.cminy, cz = az - G.cminz;
+    auto outside = [](int c, int e) { return c < 0 ? -c : (c > e - 1 ? c - (e - 1) : 0); };
+    auto reach = [](int c, int e) { return max(c, e - 1 - c); };
+    const int k0 = max(outside(cx, G.ex), max(outside(cy, G.ey), outside(cz, G.ez)));
+    const int k1 = max(reach(cx, G.ex), max(reach(cy, G.ey), reach(cz, G.ez)));
+    for (int k = k0; k <= k1; ++k) {
+        const int z0 = max(cz - k, 0), z1 = min(cz + k, G.ez - 1);
+        const int y0 = max(cy - k, 0), y1 = min(cy + k, G.ey - 1);
+        const int x0 = max(cx - k, 0), x1 = min(cx + k, G.ex - 1);
+        for (int z = z0; z <= z1; ++z) {
+            const bool zedge = (z == cz - k) || (z == cz + k);
+            for (int y = y0; y <= y1; ++y) {
+                if (zedge || y == cy - k || y == cy + k) {
+                    for (int x = x0; x <= x1; ++x) visit_cell(G, x, y, z, qx, qy, qz, best, bid, bpos);
+                } else {
+                    if (cx - k >= 0 && cx - k < G.ex) visit_cell(G, cx - k, y, z, qx, qy, qz, best, bid, bpos);
+                    if (cx + k >= 0 && cx + k < G.ex) visit_cell(G, cx + k, y, z, qx, qy, qz, best, bid, bpos);
+                }
+            }
+        }
+        // everything not yet visited lies outside the cube of cells [c-k, c+k]^3
+        const double mx = fmin(qx - (double)(ax - k) * G.cell, (double)(ax + k + 1) * G.cell - qx);
+        const double my = fmin(qy - (double)(ay - k) * G.cell, (double)(ay + k + 1) * G.cell - qy);
+        const double mz = fmin(qz - (double)(az - k) * G.cell, (double)(az + k + 1) * G.cell - qz);
+        const double m = fmin(mx, fmin(my, mz)) - G.eps;
+        if (m > 0.0 && best < m * m) break;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+k_grid_nn(const GridView G, const double* __restrict__ src, size_t m, double max_d2,
+          double* __restrict__ nn_d, long long* __restrict__ nn_idx, int* __restrict__ nn_pos) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    double best = max_d2;
+    long long bid;
+    int bpos;
+    grid_nn(G, src[3 * i + 0], src[3 * i + 1], src[3 * i + 2], best, bid, bpos);
+    nn_d[i] = (bid >= 0) ? sqrt(best) : INFINITY;
+    nn_idx[i] = bid;
+    nn_pos[i] = bpos;
+}
+
+// ------------------------------------------------------------------------------------------
+// trimmed Kabsch step (icp_step_KD): selection of the `taken` smallest distances, sums
+// ------------------------------------------------------------------------------------------
+
+struct SelState { unsigned long long prefix, remaining, thr, take_equal; };
+
+__global__ void k_sel_init(SelState* s, unsigned long long taken) {
+    s->prefix = 0; s->remaining = taken; s->thr = 0; s->take_equal = 0;
+}
+
+__global__ void __launch_bounds__(256)
+k_sel_hist(const double* __restrict__ d, size_t m, int shift, const SelState* __restrict__ s, unsigned* __restrict__ hist) {
+    __shared__ unsigned h[256];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const unsigned long long prefix = s->prefix;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += (size_t)gridDim.x * blockDim.x) {
+        const unsigned long long b = (unsigned long long)__double_as_longlong(d[i]);
+        const bool match = (shift == 56) || ((b >> (shift + 8)) == (prefix >> (shift + 8)));
+        if (match) atomicAdd(&h[(unsigned)(b >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    if (h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], h[threadIdx.x]);
+}
+
+__global__ void k_sel_pick(unsigned* __restrict__ hist, SelState* __restrict__ s, int shift) {
+    if (threadIdx.x == 0 && s->remaining > 0) {
+        unsigned long long cum = 0;
+        for (int dgt = 0; dgt < 256; ++dgt) {
+            const unsigned long long c = hist[dgt];
+            if (cum + c >= s->remaining) {
+                s->remaining -= cum;
+                s->prefix |= (unsigned long long)dgt << shift;
+                break;
+            }
+            cum += c;
+        }
+        if (shift == 0) { s->thr = s->prefix; s->take_equal = s->remaining; }
+    }
+    __syncthreads();
+    hist[threadIdx.x] = 0;
+}
+
+// sel[i] = 1 for the `taken` smallest distances; equal distances at the threshold are
+// taken in index order.  One block walks the array in order.
+__global__ void __launch_bounds__(1024)
+k_sel_mark(const double* __restrict__ d, size_t m, const SelState* __restrict__ s, unsigned long long taken,
+           unsigned char* __restrict__ sel) {
+    __shared__ unsigned wsum[16];
+    __shared__ unsigned long long running;
+    if (threadIdx.x == 0) running = 0;
+    __syncthreads();
+    const unsigned long long thr = s->thr, take_equal = s->take_equal;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (size_t base = 0; base < m; base += 1024) {
+        const size_t i = base + threadIdx.x;
+        const unsigned long long b = (i < m) ? (unsigned long long)__double_as_longlong(d[i]) : ~0ull;
+        const bool eq = (i < m) && b == thr;
+        const unsigned long long bal = __ballot(eq);
+        const unsigned in_wave = (unsigned)__popcll(bal & ((1ull << lane) - 1ull));
+        if (lane == 0) wsum[w] = (unsigned)__popcll(bal);
+        __syncthreads();
+        unsigned before = 0, total = 0;
+        for (int j = 0; j < 16; ++j) { if (j < w) before += wsum[j]; total += wsum[j]; }
+        const unsigned long long rank = running + before + in_wave;
+        if (i < m) sel[i] = (taken > 0 && (b < thr || (eq && rank < take_equal))) ? 1 : 0;
+        __syncthreads();
+        if (threadIdx.x == 0) running += total;
+        __syncthreads();
+    }
+}
+
+// PASS 0: sums of the matched map points, of the source points, and the count (7 values).
+// PASS 1: W[i][j] = sum (ref_i - mean_ref_i)(other_j - mean_other_j) (9 values); means at mean[0..6).
+constexpr int KD_BLOCKS = 512;
+template <int PASS>
+__global__ void __launch_bounds__(256)
+k_kd_sum(const GridPoint* __restrict__ pts, const int* __restrict__ nn_pos, const double* __restrict__ src,
+         const unsigned char* __restrict__ sel, size_t m, const double* __restrict__ mean, double* __restrict__ partial) {
+    constexpr int V = PASS == 0 ? 7 : 9;
+    __shared__ double red[256];
+    double acc[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) acc[v] = 0.0;
+    double mr[3] = {0, 0, 0}, mo[3] = {0, 0, 0};
+    if (PASS == 1) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { mr[a] = mean[a]; mo[a] = mean[3 + a]; }
+    }
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += (size_t)gridDim.x * blockDim.x) {
+        const int p = nn_pos[i];
+        if (!sel[i] || p < 0) continue;
+        const double r[3] = {pts[p].x, pts[p].y, pts[p].z};
+        const double o[3] = {src[3 * i + 0], src[3 * i + 1], src[3 * i + 2]};
+        if (PASS == 0) {
+#pragma unroll
+            for (int a = 0; a < 3; ++a) { acc[a] += r[a]; acc[3 + a] += o[a]; }
+            acc[6] += 1.0;
+        } else {
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int b = 0; b < 3; ++b) acc[a * 3 + b] += (r[a] - mr[a]) * (o[b] - mo[b]);
+        }
+    }
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+        red[threadIdx.x] = acc[v];
+        __syncthreads();
+        for (int s = 128; s > 0; s >>= 1) {
+            if (threadIdx.x < (unsigned)s) red[threadIdx.x] += red[threadIdx.x + s];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) partial[(size_t)blockIdx.x * 16 + v] = red[0];
+        __syncthreads();
+    }
+}
+
+// out[0..V) = sums over the blocks in block order; PASS 0 also writes the six means to out[16..22).
+template <int PASS>
+__global__ void k_kd_final(const double* __restrict__ partial, int blocks, double* __restrict__ out) {
+    constexpr int V = PASS == 0 ? 7 : 9;
+    __shared__ double s[16];
+    const int v = threadIdx.x;
+    if (v < V) {
+        double acc = 0.0;
+        for (int b = 0; b < blocks; ++b) acc += partial[(size_t)b * 16 + v];
+        s[v] = acc;
+        out[PASS * 32 + v] = acc;
+    }
+    __syncthreads();
+    if (PASS == 0 && v < 6) out[16 + v] = s[v] / s[6];
+}
+
+// p <- R p + sign * t on the working copy (applyIcpStep, PointcloudIcpContainer.py:315-317, sign = +1;
+// apply_iteration_of_ls, :172-174, sign = -1).
+__global__ void k_src_apply(double* __restrict__ src, size_t m, const double* __restrict__ Rt, double sign) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    const double px = src[3 * i + 0], py = src[3 * i + 1], pz = src[3 * i + 2];
+    src[3 * i + 0] = ((Rt[0] * px + Rt[1] * py) + Rt[2] * pz) + sign * Rt[9];
+    src[3 * i + 1] = ((Rt[3] * px + Rt[4] * py) + Rt[5] * pz) + sign * Rt[10];
+    src[3 * i + 2] = ((Rt[6] * px + Rt[7] * py) + Rt[8] * pz) + sign * Rt[11];
+}
+
+// ------------------------------------------------------------------------------------------
+// scan-to-map least squares: exact neighbour within the search radius, then the
+// tile arithmetic of LeastSquaresPoint.glsl / LeastSquaresPlane.glsl on the float32
+// casts, summed by the ParalellHBSum tree (one wave = one shader workgroup).
+// Only source points whose cell key lies in [own_lo, own_hi) contribute: with the
+// key space split over ranks and a one-cell halo of map points on every rank, the
+// rank partials add up to the whole sum.
+// ------------------------------------------------------------------------------------------
+
+struct MapLsArgs {
+    GridView G;
+    const float4* normals;
+    double* src;
+    IcpState* st;
+    size_t m;
+    double radius2;
+    unsigned long long own_lo, own_hi;
+    float* partials;
+    long long* nn_idx;        // optional per-point outputs
+    double* nn_d;
+};
+
+template <int MODE>
+__global__ void __launch_bounds__(PCP_BLOCK) k_map_ls(const MapLsArgs A) {
+    IcpState* __restrict__ st = A.st;
+    if (st->done) return;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool in = i < A.m;
+    float v[PCP_NVAL];
+#pragma unroll
+    for (int k = 0; k < PCP_NVAL; ++k) v[k] = 0.0f;
+    if (in) {
+        double px = A.src[3 * i + 0], py = A.src[3 * i + 1], pz = A.src[3 * i + 2];
+        if (st->pending) {
+            const double nx = ((st->R[0] * px + st->R[1] * py) + st->R[2] * pz) - st->t[0];
+            const double ny = ((st->R[3] * px + st->R[4] * py) + st->R[5] * pz) - st->t[1];
+            const double nz = ((st->R[6] * px + st->R[7] * py) + st->R[8] * pz) - st->t[2];
+            px = nx; py = ny; pz = nz;
+        }
+        if (st->pending) { A.src[3 * i + 0] = px; A.src[3 * i + 1] = py; A.src[3 * i + 2] = pz; }
+        const unsigned long long key = morton3((unsigned)(cell_of(px, A.G.cell) + COORD_BIAS),
+                                               (unsigned)(cell_of(py, A.G.cell) + COORD_BIAS),
+                                               (unsigned)(cell_of(pz, A.G.cell) + COORD_BIAS));
+        long long bid = -1;
+        int bpos = -1;
+        double best = A.radius2;
+        if (key >= A.own_lo && key < A.own_hi) grid_nn(A.G, px, py, pz, best, bid, bpos);
+        if (A.nn_idx) { A.nn_idx[i] = bid; A.nn_d[i] = (bid >= 0) ? sqrt(best) : INFINITY; }
+        if (bid >= 0) {
+            const GridPoint p = A.G.pts[bpos];
+            const float4 pa = make_float4((float)p.x, (float)p.y, (float)p.z, 0.0f);
+            const float4 q = make_float4((float)px, (float)py, (float)pz, 0.0f);
+            const float d = distsq(q, pa);
+            if (MODE == PCP_MODE_POINT) ls_point_values(pa, q, d, v);
+            else ls_plane_values(pa, q, A.normals[bpos], d, v);
+        }
+    }
+    const int lane = threadIdx.x & 63;
+    const size_t wave = i >> 6;
+    if ((wave << 6) < A.m) {
+#pragma unroll
+        for (int k = 0; k < PCP_NVAL; ++k) v[k] = wave_tree_sum(v[k]);
+        float mine = 0.0f;
+#pragma unroll
+        for (int k = 0; k < PCP_NVAL; ++k) {
+            const float vk = __shfl(v[k], 0, 64);
+            mine = (lane == k) ? vk : mine;
+        }
+        if (lane < PCP_PSTRIDE) A.partials[wave * PCP_PSTRIDE + lane] = mine;
+    }
+}
+
+__global__ void __launch_bounds__(1024)
+k_map_finish(const FinishArgs F, int solve, int mode, int max_iter, float tol, int full_iter) {
+    finish_body(F, solve, mode, max_iter, tol, full_iter);
+}
+
+// The host half of one iteration from an already summed (all-reduced) 8x8 tile.
+__global__ void k_map_pose(const float* __restrict__ tile, IcpState* __restrict__ st, float* __restrict__ hb_trace,
+                           float* __restrict__ dx_trace, int mode, int max_iter, float tol, int full_iter) {
+    if (threadIdx.x != 0 || st->done) return;
+    const int it = st->iter;
+    float v[PCP_NVAL];
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+#pragma unroll
+        for (int c = r; c < 6; ++c) v[tri(r, c)] = tile[r * 8 + c];
+        v[21 + r] = tile[r * 8 + 6];
+    }
+    for (int k = 0; k < 64; ++k) hb_trace[(size_t)it * 64 + k] = tile[k];
+    pose_step(v, st, dx_trace, it, mode, max_iter, tol, full_iter);
+}
+
+__global__ void k_map_apply_pending(double* __restrict__ src, size_t m, IcpState* __restrict__ st) {
+    if (!st->pending) return;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    const double px = src[3 * i + 0], py = src[3 * i + 1], pz = src[3 * i + 2];
+    src[3 * i + 0] = ((st->R[0] * px + st->R[1] * py) + st->R[2] * pz) - st->t[0];
+    src[3 * i + 1] = ((st->R[3] * px + st->R[4] * py) + st->R[5] * pz) - st->t[1];
+    src[3 * i + 2] = ((st->R[6] * px + st->R[7] * py) + st->R[8] * pz) - st->t[2];
+}
+
+__global__ void k_map_state(IcpState* __restrict__ st, int reset) {
+    if (reset) { st->iter = 0; st->done = 0; st->converged = 0; st->singular = 0; }
+    st->pending = 0;
+}
+
+inline unsigned blocks_for(size_t n, int threads) { return (unsigned)((n + threads - 1) / threads); }
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------
+
+struct pcp_grid {
+    int device = 0;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    // map
+    size_t n = 0, cap = 0;
+    double cell = 0.0;
+    int cmin[3] = {0, 0, 0}, ext[3] = {0, 0, 0};
+    GridPoint* pts = nullptr;
+    float4* normals = nullptr;
+    bool have_normals = false;
+    Cell* table = nullptr;
+    int log_cap = 0;
+    size_t table_cap = 0;
+    unsigned long long n_cells = 0;
+    int sort_passes = 0;
+    float build_ms = 0.0f, sort_ms = 0.0f;
+    // source
+    size_t m = 0, m_cap = 0;
+    double *src_in = nullptr, *src = nullptr, *nn_d = nullptr;
+    long long* nn_idx = nullptr;
+    int* nn_pos = nullptr;
+    unsigned char* sel = nullptr;
+    float *partials = nullptr, *lvl0 = nullptr, *lvl1 = nullptr;
+    // small state
+    IcpState* state = nullptr;
+    float *hb_trace = nullptr, *dx_trace = nullptr, *tile = nullptr;
+    SelState* sel_state = nullptr;
+    unsigned* sel_hist = nullptr;
+    double *kd_partial = nullptr, *kd_out = nullptr, *rt = nullptr;
+    int* mm = nullptr;
+    unsigned long long* cell_count = nullptr;
+    unsigned long long own_lo = 0, own_hi = 1ull << 63;
+    bool nn_valid = false;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
+    static const int max_iter_cap = 1024;
+};
+
+namespace {
+
+GridView view_of(const pcp_grid* g) {
+    GridView G;
+    G.pts = g->pts; G.table = g->table; G.log_cap = g->log_cap; G.n = g->n;
+    G.cell = g->cell; G.eps = g->cell * 1e-7;
+    G.cminx = g->cmin[0]; G.cminy = g->cmin[1]; G.cminz = g->cmin[2];
+    G.ex = g->ext[0]; G.ey = g->ext[1]; G.ez = g->ext[2];
+    return G;
+}
+
+int free_map(pcp_grid* g) {
+    if (g->pts) PCP_CHECK(hipFree(g->pts));
+    if (g->normals) PCP_CHECK(hipFree(g->normals));
+    if (g->table) PCP_CHECK(hipFree(g->table));
+    g->pts = nullptr; g->normals = nullptr; g->table = nullptr;
+    g->cap = 0; g->table_cap = 0; g->n = 0;
+    return 0;
+}
+
+int free_source(pcp_grid* g) {
+    void* p[] = {g->src_in, g->src, g->nn_d, g->nn_idx, g->nn_pos, g->sel, g->partials, g->lvl0, g->lvl1};
+    for (void* q : p) if (q) PCP_CHECK(hipFree(q));
+    g->src_in = g->src = g->nn_d = nullptr; g->nn_idx = nullptr; g->nn_pos = nullptr; g->sel = nullptr;
+    g->partials = g->lvl0 = g->lvl1 = nullptr;
+    g->m_cap = 0; g->m = 0;
+    return 0;
+}
+
+int reserve_source(pcp_grid* g, size_t m) {
+    if (m <= g->m_cap) return 0;
+    if (free_source(g)) return 1;
+    const size_t cap = std::max<size_t>(m, 1024);
+    const size_t waves = (cap + 63) / 64, l1 = (waves + 63) / 64 + 1;
+    PCP_CHECK(hipMalloc(&g->src_in, cap * 24));
+    PCP_CHECK(hipMalloc(&g->src, cap * 24));
+    PCP_CHECK(hipMalloc(&g->nn_d, cap * 8));
+    PCP_CHECK(hipMalloc(&g->nn_idx, cap * 8));
+    PCP_CHECK(hipMalloc(&g->nn_pos, cap * 4));
+    PCP_CHECK(hipMalloc(&g->sel, cap));
+    PCP_CHECK(hipMalloc(&g->partials, waves * PCP_PSTRIDE * 4));
+    PCP_CHECK(hipMalloc(&g->lvl0, l1 * PCP_PSTRIDE * 4));
+    PCP_CHECK(hipMalloc(&g->lvl1, l1 * PCP_PSTRIDE * 4));
+    g->m_cap = cap;
+    return 0;
+}
+
+int check_source(const pcp_grid* g) {
+    if (!g) return pcp_fail("null grid");
+    if (g->m == 0) return pcp_fail("no source cloud uploaded (pcp_grid_source)");
+    return 0;
+}
+
+MapLsArgs map_args(pcp_grid* g, double radius, bool per_point) {
+    MapLsArgs A;
+    A.G = view_of(g);
+    A.normals = g->normals;
+    A.src = g->src; A.st = g->state; A.m = g->m;
+    A.radius2 = radius * radius;
+    A.own_lo = g->own_lo; A.own_hi = g->own_hi;
+    A.partials = g->partials;
+    A.nn_idx = per_point ? g->nn_idx : nullptr;
+    A.nn_d = per_point ? g->nn_d : nullptr;
+    return A;
+}
+
+int launch_map_ls(pcp_grid* g, int mode, double radius, bool per_point) {
+    if (mode != PCP_MODE_POINT && mode != PCP_MODE_PLANE) return pcp_fail("unknown mode %d", mode);
+    if (mode == PCP_MODE_PLANE && !g->have_normals) return pcp_fail("plane mode needs map normals (pcp_grid_build)");
+    if (!(radius > 0.0)) return pcp_fail("search radius must be positive");
+    const MapLsArgs A = map_args(g, radius, per_point);
+    const unsigned blocks = blocks_for(g->m, PCP_BLOCK);
+    if (mode == PCP_MODE_POINT) hipLaunchKernelGGL(k_map_ls<PCP_MODE_POINT>, dim3(blocks), dim3(PCP_BLOCK), 0, g->stream, A);
+    else hipLaunchKernelGGL(k_map_ls<PCP_MODE_PLANE>, dim3(blocks), dim3(PCP_BLOCK), 0, g->stream, A);
+    PCP_CHECK(hipGetLastError());
+    return 0;
+}
+
+FinishArgs map_finish_args(pcp_grid* g, float* hb_out) {
+    FinishArgs F;
+    F.partials = g->partials; F.n1 = (int)((g->m + 63) / 64); F.lvl0 = g->lvl0; F.lvl1 = g->lvl1;
+    F.st = g->state; F.hb_out = hb_out; F.dx_out = g->dx_trace;
+    return F;
+}
+
+}  // namespace
+
+extern "C" {
+
+int pcp_grid_create(int device, pcp_grid** out) {
+    if (!out) return pcp_fail("out is null");
+    *out = nullptr;
+    int count = 0;
+    PCP_CHECK(hipGetDeviceCount(&count));
+    if (device < 0 || device >= count) return pcp_fail("device %d out of range (%d devices)", device, count);
+    PCP_CHECK(hipSetDevice(device));
+    pcp_grid* g = new pcp_grid();
+    g->device = device;
+    PCP_CHECK(hipStreamCreateWithFlags(&g->own_stream, hipStreamNonBlocking));
+    g->stream = g->own_stream;
+    PCP_CHECK(hipMalloc(&g->state, sizeof(IcpState)));
+    PCP_CHECK(hipMemset(g->state, 0, sizeof(IcpState)));
+    PCP_CHECK(hipMalloc(&g->hb_trace, (size_t)pcp_grid::max_iter_cap * 64 * 4));
+    PCP_CHECK(hipMalloc(&g->dx_trace, (size_t)pcp_grid::max_iter_cap * 6 * 4));
+    PCP_CHECK(hipMalloc(&g->tile, 64 * 4));
+    PCP_CHECK(hipMalloc(&g->sel_state, sizeof(SelState)));
+    PCP_CHECK(hipMalloc(&g->sel_hist, 256 * 4));
+    PCP_CHECK(hipMemset(g->sel_hist, 0, 256 * 4));
+    PCP_CHECK(hipMalloc(&g->kd_partial, (size_t)KD_BLOCKS * 16 * 8));
+    PCP_CHECK(hipMalloc(&g->kd_out, 64 * 8));
+    PCP_CHECK(hipMalloc(&g->rt, 12 * 8));
+    PCP_CHECK(hipMalloc(&g->mm, 8 * 4));
+    PCP_CHECK(hipMalloc(&g->cell_count, 8));
+    PCP_CHECK(hipEventCreate(&g->ev0));
+    PCP_CHECK(hipEventCreate(&g->ev1));
+    PCP_CHECK(hipEventCreate(&g->ev2));
+    PCP_CHECK(hipEventCreate(&g->ev3));
+    *out = g;
+    return 0;
+}
+
+int pcp_grid_destroy(pcp_grid* g) {
+    if (!g) return 0;
+    PCP_CHECK(hipSetDevice(g->device));
+    PCP_CHECK(hipStreamSynchronize(g->stream));
+    if (free_map(g) || free_source(g)) return 1;
+    void* p[] = {g->state, g->hb_trace, g->dx_trace, g->tile, g->sel_state, g->sel_hist, g->kd_partial, g->kd_out,
+                 g->rt, g->mm, g->cell_count};
+    for (void* q : p) if (q) PCP_CHECK(hipFree(q));
+    for (hipEvent_t e : {g->ev0, g->ev1, g->ev2, g->ev3}) if (e) PCP_CHECK(hipEventDestroy(e));
+    PCP_CHECK(hipStreamDestroy(g->own_stream));
+    delete g;
+    return 0;
+}
+
+int pcp_grid_set_stream(pcp_grid* g, void* hip_stream) {
+    if (!g) return pcp_fail("null grid");
+    g->stream = hip_stream ? (hipStream_t)hip_stream : g->own_stream;
+    return 0;
+}
+
+int pcp_grid_synchronize(pcp_grid* g) {
+    if (!g) return pcp_fail("null grid");
+    PCP_CHECK(hipSetDevice(g->device));
+    PCP_CHECK(hipStreamSynchronize(g->stream));
+    return 0;
+}
+
+int pcp_grid_build(pcp_grid* g, const double* xyz, size_t n, double cell, const float* normals_xyzw) {
+    if (!g) return pcp_fail("null grid");
+    if (!(cell > 0.0) || !std::isfinite(cell)) return pcp_fail("cell size must be positive and finite");
+    if (n >= (1ull << 31)) return pcp_fail("%zu map points exceed the 2^31 limit of one grid", n);
+    if (n && !xyz) return pcp_fail("xyz is null");
+    PCP_CHECK(hipSetDevice(g->device));
+    hipStream_t s = g->stream;
+    PCP_CHECK(hipStreamSynchronize(s));
+    if (free_map(g)) return 1;
+    g->cell = cell;
+    g->have_normals = false;
+    g->n_cells = 0;
+    g->sort_passes = 0;
+    g->ext[0] = g->ext[1] = g->ext[2] = 0;
+    g->nn_valid = false;
+    if (n == 0) return 0;
+
+    double* d_xyz = nullptr;
+    float4* d_nrm = nullptr;
+    unsigned long long *k0 = nullptr, *k1 = nullptr;
+    unsigned *v0 = nullptr, *v1 = nullptr, *hist = nullptr, *totals = nullptr, *base = nullptr;
+    const int nblk = (int)((n + RS_TILE - 1) / RS_TILE);
+    auto cleanup = [&]() {
+        for (void* q : {(void*)d_xyz, (void*)d_nrm, (void*)k0, (void*)k1, (void*)v0, (void*)v1, (void*)hist,
+                        (void*)totals, (void*)base})
+            if (q) (void)hipFree(q);
+    };
+#define GRID_TRY(expr)                                                                                      \
+    do {                                                                                                    \
+        hipError_t e_ = (expr);                                                                             \
+        if (e_ != hipSuccess) {                                                                             \
+            cleanup();                                                                                      \
+            return pcp_fail("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__);     \
+        }                                                                                                   \
+    } while (0)
+    GRID_TRY(hipMalloc(&d_xyz, n * 24));
+    GRID_TRY(hipMemcpyAsync(d_xyz, xyz, n * 24, hipMemcpyHostToDevice, s));
+    if (normals_xyzw) {
+        GRID_TRY(hipMalloc(&d_nrm, n * 16));
+        GRID_TRY(hipMemcpyAsync(d_nrm, normals_xyzw, n * 16, hipMemcpyHostToDevice, s));
+    }
+    GRID_TRY(hipEventRecord(g->ev0, s));
+    // cell range
+    const int init[8] = {INT_MAX, INT_MAX, INT_MAX, INT_MIN, INT_MIN, INT_MIN, 0, 0};
+    GRID_TRY(hipMemcpyAsync(g->mm, init, sizeof(init), hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_cell_range, dim3(blocks_for(n, 256)), dim3(256), 0, s, d_xyz, n, cell, g->mm);
+    int mm[8];
+    GRID_TRY(hipMemcpyAsync(mm, g->mm, sizeof(mm), hipMemcpyDeviceToHost, s));
+    GRID_TRY(hipStreamSynchronize(s));
+    if (mm[6]) {
+        cleanup();
+        return pcp_fail("map coordinates must be finite and within 2^20 cells of the origin");
+    }
+    int bits = 1;
+    for (int a = 0; a < 3; ++a) {
+        g->cmin[a] = mm[a];
+        g->ext[a] = mm[3 + a] - mm[a] + 1;
+        while ((1 << bits) < g->ext[a]) ++bits;
+    }
+    const int passes = (3 * bits + 7) / 8;
+    g->sort_passes = passes;
+    // keys + sort
+    GRID_TRY(hipMalloc(&k0, n * 8));
+    GRID_TRY(hipMalloc(&k1, n * 8));
+    GRID_TRY(hipMalloc(&v0, n * 4));
+    GRID_TRY(hipMalloc(&v1, n * 4));
+    GRID_TRY(hipMalloc(&hist, (size_t)256 * nblk * 4));
+    GRID_TRY(hipMalloc(&totals, 256 * 4));
+    GRID_TRY(hipMalloc(&base, 256 * 4));
+    hipLaunchKernelGGL(k_cell_keys, dim3(blocks_for(n, 256)), dim3(256), 0, s, d_xyz, n, cell, g->cmin[0], g->cmin[1],
+                       g->cmin[2], k0, v0);
+    GRID_TRY(hipEventRecord(g->ev1, s));
+    unsigned long long *kin = k0, *kout = k1;
+    unsigned *vin = v0, *vout = v1;
+    for (int p = 0; p < passes; ++p) {
+        const int shift = 8 * p;
+        hipLaunchKernelGGL(k_rs_hist, dim3(nblk), dim3(RS_THREADS), 0, s, kin, n, shift, hist, nblk);
+        hipLaunchKernelGGL(k_rs_scan, dim3(256), dim3(256), 0, s, hist, nblk, totals);
+        hipLaunchKernelGGL(k_rs_base, dim3(1), dim3(256), 0, s, totals, base);
+        hipLaunchKernelGGL(k_rs_scatter, dim3(nblk), dim3(RS_THREADS), 0, s, kin, vin, n, shift, hist, base, nblk, kout, vout);
+        std::swap(kin, kout);
+        std::swap(vin, vout);
+    }
+    GRID_TRY(hipEventRecord(g->ev2, s));
+    GRID_TRY(hipGetLastError());
+    // occupied cells -> hash table
+    GRID_TRY(hipMemsetAsync(g->cell_count, 0, 8, s));
+    hipLaunchKernelGGL(k_count_cells, dim3(blocks_for(n, 256)), dim3(256), 0, s, kin, n, g->cell_count);
+    unsigned long long cells = 0;
+    GRID_TRY(hipMemcpyAsync(&cells, g->cell_count, 8, hipMemcpyDeviceToHost, s));
+    GRID_TRY(hipStreamSynchronize(s));
+    g->n_cells = cells;
+    int log_cap = 4;
+    while ((1ull << log_cap) < 2 * cells) ++log_cap;
+    g->log_cap = log_cap;
+    g->table_cap = (size_t)1 << log_cap;
+    GRID_TRY(hipMalloc(&g->table, g->table_cap * sizeof(Cell)));
+    GRID_TRY(hipMemsetAsync(g->table, 0xFF, g->table_cap * sizeof(Cell), s));
+    hipLaunchKernelGGL(k_insert_cells, dim3(blocks_for(n, 256)), dim3(256), 0, s, kin, n, g->table, log_cap);
+    hipLaunchKernelGGL(k_close_cells, dim3(blocks_for(n, 256)), dim3(256), 0, s, kin, n, g->table, log_cap);
+    GRID_TRY(hipMalloc(&g->pts, n * sizeof(GridPoint)));
+    if (d_nrm) GRID_TRY(hipMalloc(&g->normals, n * 16));
+    hipLaunchKernelGGL(k_gather_points, dim3(blocks_for(n, 256)), dim3(256), 0, s, d_xyz, vin, n, d_nrm, g->pts, g->normals);
+    GRID_TRY(hipEventRecord(g->ev3, s));
+    GRID_TRY(hipGetLastError());
+    GRID_TRY(hipStreamSynchronize(s));
+    GRID_TRY(hipEventElapsedTime(&g->build_ms, g->ev0, g->ev3));
+    GRID_TRY(hipEventElapsedTime(&g->sort_ms, g->ev1, g->ev2));
+#undef GRID_TRY
+    cleanup();
+    g->n = n;
+    g->cap = n;
+    g->have_normals = normals_xyzw != nullptr;
+    return 0;
+}
+
+int pcp_grid_info(pcp_grid* g, unsigned long long* n_points, unsigned long long* n_cells, int* extent3,
+                  int* sort_passes, float* build_ms, float* sort_ms) {
+    if (!g) return pcp_fail("null grid");
+    if (n_points) *n_points = g->n;
+    if (n_cells) *n_cells = g->n_cells;
+    if (extent3) for (int a = 0; a < 3; ++a) extent3[a] = g->ext[a];
+    if (sort_passes) *sort_passes = g->sort_passes;
+    if (build_ms) *build_ms = g->build_ms;
+    if (sort_ms) *sort_ms = g->sort_ms;
+    return 0;
+}
+
+int pcp_grid_sorted_ids(pcp_grid* g, long long* ids, double* xyz) {
+    if (!g) return pcp_fail("null grid");
+    PCP_CHECK(hipSetDevice(g->device));
+    std::vector<GridPoint> h(g->n);
+    if (g->n) PCP_CHECK(hipMemcpy(h.data(), g->pts, g->n * sizeof(GridPoint), hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < g->n; ++i) {
+        if (ids) ids[i] = h[i].id;
+        if (xyz) { xyz[3 * i] = h[i].x; xyz[3 * i + 1] = h[i].y; xyz[3 * i + 2] = h[i].z; }
+    }
+    return 0;
+}
+
+int pcp_grid_source(pcp_grid* g, const double* xyz, size_t m) {
+    if (!g) return pcp_fail("null grid");
+    if (m == 0 || !xyz) return pcp_fail("empty source cloud");
+    if (m >= (1ull << 31)) return pcp_fail("%zu source points exceed the 2^31 limit", m);
+    PCP_CHECK(hipSetDevice(g->device));
+    PCP_CHECK(hipStreamSynchronize(g->stream));
+    if (reserve_source(g, m)) return 1;
+    g->m = m;
+    g->nn_valid = false;
+    PCP_CHECK(hipMemcpyAsync(g->src_in, xyz, m * 24, hipMemcpyHostToDevice, g->stream));
+    PCP_CHECK(hipMemcpyAsync(g->src, g->src_in, m * 24, hipMemcpyDeviceToDevice, g->stream));
+    hipLaunchKernelGGL(k_map_state, dim3(1), dim3(1), 0, g->stream, g->state, 1);
+    PCP_CHECK(hipStreamSynchronize(g->stream));
+    return 0;
+}
+
+int pcp_grid_source_rewind(pcp_grid* g) {
+    if (check_source(g)) return 1;
+    PCP_CHECK(hipSetDevice(g->device));
+    PCP_CHECK(hipMemcpyAsync(g->src, g->src_in, g->m * 24, hipMemcpyDeviceToDevice, g->stream));
+    hipLaunchKernelGGL(k_map_state, dim3(1), dim3(1), 0, g->stream, g->state, 1);
+    PCP_CHECK(hipGetLastError());
+    g->nn_valid = false;
+    return 0;
+}
+
+int pcp_grid_source_read(pcp_grid* g, double* xyz) {
+    if (check_source(g)) return 1;
+    if (!xyz) return pcp_fail("xyz is null");
+    PCP_CHECK(hipSetDevice(g->device));
+    PCP_CHECK(hipMemcpyAsync(xyz, g->src, g->m * 24, hipMemcpyDeviceToHost, g->stream));
+    PCP_CHECK(hipStreamSynchronize(g->stream));
+    return 0;
+}
+
+int pcp_grid_source_apply(pcp_grid* g, const double* R9, const double* t3, int minus_t) {
+    if (check_source(g)) return 1;
+    if (!R9 || !t3) return pcp_fail("R or t is null");
+    PCP_CHECK(hipSetDevice(g->device));
+    double rt[12];
+    memcpy(rt, R9, 72);
+    memcpy(rt + 9, t3, 24);
+    PCP_CHECK(hipStreamSynchronize(g->stream));
+    PCP_CHECK(hipMemcpyAsync(g->rt, rt, sizeof(rt), hipMemcpyHostToDevice, g->stream));
+    hipLaunchKernelGGL(k_src_apply, dim3(blocks_for(g->m, 256)), dim3(256), 0, g->stream, g->src, g->m, g->rt,
+                       minus_t ? -1.0 : 1.0);
+    PCP_CHECK(hipGetLastError());
+    PCP_CHECK(hipStreamSynchronize(g->stream));
+    g->nn_valid = false;
+    return 0;
+}
+
+int pcp_grid_query_resident(pcp_grid* g, double max_dist, long long* idx, double* dist, float* kernel_ms) {
+    if (check_source(g)) return 1;
+    PCP_CHECK(hipSetDevice(g->device));
+    const double max_d2 = (max_dist > 0.0 && std::isfinite(max_dist)) ? max_dist * max_dist : INFINITY;
+    PCP_CHECK(hipEventRecord(g->ev0, g->stream));
+    hipLaunchKernelGGL(k_grid_nn, dim3(blocks_for(g->m, 256)), dim3(256), 0, g->stream, view_of(g), g->src, g->m, max_d2,
+                       g->nn_d, g->nn_idx, g->nn_pos);
+    PCP_CHECK(hipGetLastError());
+    PCP_CHECK(hipEventRecord(g->ev1, g->stream));
+    if (idx) PCP_CHECK(hipMemcpyAsync(idx, g->nn_idx, g->m * 8, hipMemcpyDeviceToHost, g->stream));
+    if (dist) PCP_CHECK(hipMemcpyAsync(dist, g->nn_d, g->m * 8, hipMemcpyDeviceToHost, g->stream));
+    PCP_CHECK(hipStreamSynchronize(g->stream));
+    if (kernel_ms) PCP_CHECK(hipEventElapsedTime(kernel_ms, g->ev0, g->ev1));
+    g->nn_valid = true;
+    return 0;
+}
+
+int pcp_grid_query(pcp_grid* g, const double* q_xyz, size_t m, double max_dist, long long* idx, double* dist) {
+    if (pcp_grid_source(g, q_xyz, m)) return 1;
+    return pcp_grid_query_resident(g, max_dist, idx, dist, nullptr);
+}
+
+int pcp_grid_kd_step(pcp_grid* g, double keep_fraction, double* mean_ref, double* mean_other, double* W9,
+                     unsigned long long* taken_out) {
+    if (check_source(g)) return 1;
+    if (g->n == 0) return pcp_fail("the map is empty");
+    if (!(keep_fraction > 0.0 && keep_fraction <= 1.0)) return pcp_fail("keep_fraction must be in (0, 1]");
+    PCP_CHECK(hipSetDevice(g->device));
+    hipStream_t s = g->stream;
+    const size_t m = g->m;
+    const unsigned long long taken = (unsigned long long)((double)m * keep_fraction);    // int(len * percent)
+    if (taken == 0) return pcp_fail("keep_fraction selects no point");
+    hipLaunchKernelGGL(k_grid_nn, dim3(blocks_for(m, 256)), dim3(256), 0, s, view_of(g), g->src, m, (double)INFINITY,
+                       g->nn_d, g->nn_idx, g->nn_pos);
+    hipLaunchKernelGGL(k_sel_init, dim3(1), dim3(1), 0, s, g->sel_state, taken);
+    const unsigned hb = std::min<unsigned>(blocks_for(m, 256), 1024);
+    for (int shift = 56; shift >= 0; shift -= 8) {
+        hipLaunchKernelGGL(k_sel_hist, dim3(hb), dim3(256), 0, s, g->nn_d, m, shift, g->sel_state, g->sel_hist);
+        hipLaunchKernelGGL(k_sel_pick, dim3(1), dim3(256), 0, s, g->sel_hist, g->sel_state, shift);
+    }
+    hipLaunchKernelGGL(k_sel_mark, dim3(1), dim3(1024), 0, s, g->nn_d, m, g->sel_state, taken, g->sel);
+    const int kb = (int)std::min<size_t>(KD_BLOCKS, blocks_for(m, 256));
+    hipLaunchKernelGGL(k_kd_sum<0>, dim3(kb), dim3(256), 0, s, g->pts, g->nn_pos, g->src, g->sel, m, g->kd_out + 16, g->kd_partial);
+    hipLaunchKernelGGL(k_kd_final<0>, dim3(1), dim3(16), 0, s, g->kd_partial, kb, g->kd_out);
+    hipLaunchKernelGGL(k_kd_sum<1>, dim3(kb), dim3(256), 0, s, g->pts, g->nn_pos, g->src, g->sel, m, g->kd_out + 16, g->kd_partial);
+    hipLaunchKernelGGL(k_kd_final<1>, dim3(1), dim3(16), 0, s, g->kd_partial, kb, g->kd_out);
+    PCP_CHECK(hipGetLastError());
+    double out[64];
+    PCP_CHECK(hipMemcpyAsync(out, g->kd_out, sizeof(out), hipMemcpyDeviceToHost, s));
+    PCP_CHECK(hipStreamSynchronize(s));
+    g->nn_valid = true;
+    if ((unsigned long long)out[6] != taken)
+        return pcp_fail("trimmed set holds %.0f points, expected %llu", out[6], taken);
+    if (mean_ref) memcpy(mean_ref, out + 16, 24);
+    if (mean_other) memcpy(mean_other, out + 19, 24);
+    if (W9) memcpy(W9, out + 32, 72);
+    if (taken_out) *taken_out = taken;
+    return 0;
+}
+
+int pcp_grid_nn_read(pcp_grid* g, long long* idx, double* dist, unsigned char* selected) {
+    if (check_source(g)) return 1;
+    if (!g->nn_valid) return pcp_fail("no neighbour results resident (query or kd step first)");
+    PCP_CHECK(hipSetDevice(g->device));
+    if (idx) PCP_CHECK(hipMemcpyAsync(idx, g->nn_idx, g->m * 8, hipMemcpyDeviceToHost, g->stream));
+    if (dist) PCP_CHECK(hipMemcpyAsync(dist, g->nn_d, g->m * 8, hipMemcpyDeviceToHost, g->stream));
+    if (selected) PCP_CHECK(hipMemcpyAsync(selected, g->sel, g->m, hipMemcpyDeviceToHost, g->stream));
+    PCP_CHECK(hipStreamSynchronize(g->stream));
+    return 0;
+}
+
+int pcp_grid_set_owned_keys(pcp_grid* g, unsigned long long lo, unsigned long long hi) {
+    if (!g) return pcp_fail("null grid");
+    if (lo > hi) return pcp_fail("owned key range is empty");
+    g->own_lo = lo;
+    g->own_hi = hi;
+    return 0;
+}
+
+int pcp_grid_cell_keys(double cell, const double* xyz, size_t n, unsigned long long* keys) {
+    if (!(cell > 0.0)) return pcp_fail("cell size must be positive");
+    for (size_t i = 0; i < n; ++i) {
+        unsigned c[3];
+        for (int a = 0; a < 3; ++a) {
+            double f = floor(xyz[3 * i + a] / cell);
+            f = std::min(std::max(f, -(double)COORD_CLAMP), (double)COORD_CLAMP);
+            c[a] = (unsigned)((f == f ? (int)f : COORD_CLAMP) + COORD_BIAS);
+        }
+        keys[i] = morton3(c[0], c[1], c[2]);
+    }
+    return 0;
+}
+
+int pcp_grid_icp_reset(pcp_grid* g) {
+    if (check_source(g)) return 1;
+    PCP_CHECK(hipSetDevice(g->device));
+    hipLaunchKernelGGL(k_map_state, dim3(1), dim3(1), 0, g->stream, g->state, 1);
+    PCP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int pcp_grid_ls_dev(pcp_grid* g, int mode, double radius, float* tile_dev) {
+    if (check_source(g)) return 1;
+    if (!tile_dev) return pcp_fail("tile_dev is null");
+    PCP_CHECK(hipSetDevice(g->device));
+    if (launch_map_ls(g, mode, radius, false)) return 1;
+    hipLaunchKernelGGL(k_map_finish, dim3(1), dim3(1024), 0, g->stream, map_finish_args(g, tile_dev), 0, mode, 0, 0.0f, 0);
+    PCP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int pcp_grid_pose_dev(pcp_grid* g, const float* tile_dev, int mode, int max_iter, float tol, int full_iter) {
+    if (check_source(g)) return 1;
+    if (!tile_dev) return pcp_fail("tile_dev is null");
+    if (max_iter < 1 || max_iter > pcp_grid::max_iter_cap) return pcp_fail("max_iter must be in [1, %d]", pcp_grid::max_iter_cap);
+    PCP_CHECK(hipSetDevice(g->device));
+    hipLaunchKernelGGL(k_map_pose, dim3(1), dim3(64), 0, g->stream, tile_dev, g->state, g->hb_trace, g->dx_trace, mode,
+                       max_iter, tol, full_iter);
+    PCP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int pcp_grid_ls(pcp_grid* g, int mode, double radius, float* hb) {
+    if (check_source(g)) return 1;
+    if (!hb) return pcp_fail("hb is null");
+    PCP_CHECK(hipSetDevice(g->device));
+    hipLaunchKernelGGL(k_map_state, dim3(1), dim3(1), 0, g->stream, g->state, 1);
+    if (launch_map_ls(g, mode, radius, true)) return 1;
+    hipLaunchKernelGGL(k_map_finish, dim3(1), dim3(1024), 0, g->stream, map_finish_args(g, g->tile), 0, mode, 0, 0.0f, 0);
+    PCP_CHECK(hipGetLastError());
+    PCP_CHECK(hipMemcpyAsync(hb, g->tile, 256, hipMemcpyDeviceToHost, g->stream));
+    PCP_CHECK(hipStreamSynchronize(g->stream));
+    g->nn_valid = true;
+    return 0;
+}
+
+int pcp_grid_icp_finish(pcp_grid* g) {
+    if (check_source(g)) return 1;
+    PCP_CHECK(hipSetDevice(g->device));
+    hipLaunchKernelGGL(k_map_apply_pending, dim3(blocks_for(g->m, 256)), dim3(256), 0, g->stream, g->src, g->m, g->state);
+    hipLaunchKernelGGL(k_map_state, dim3(1), dim3(1), 0, g->stream, g->state, 0);
+    PCP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int pcp_grid_icp_fetch(pcp_grid* g, float* dx_trace, float* hb_trace, int* iters, int* converged, int* done) {
+    if (check_source(g)) return 1;
+    PCP_CHECK(hipSetDevice(g->device));
+    IcpState st;
+    PCP_CHECK(hipMemcpyAsync(&st, g->state, sizeof(st), hipMemcpyDeviceToHost, g->stream));
+    PCP_CHECK(hipStreamSynchronize(g->stream));
+    if (st.singular) return pcp_fail("singular normal equations at iteration %d", st.iter - 1);
+    const int it = std::min(st.iter, (int)pcp_grid::max_iter_cap);
+    if (dx_trace && it) PCP_CHECK(hipMemcpy(dx_trace, g->dx_trace, (size_t)it * 24, hipMemcpyDeviceToHost));
+    if (hb_trace && it) PCP_CHECK(hipMemcpy(hb_trace, g->hb_trace, (size_t)it * 256, hipMemcpyDeviceToHost));
+    if (iters) *iters = it;
+    if (converged) *converged = st.converged;
+    if (done) *done = st.done;
+    return 0;
+}
+
+int pcp_grid_icp_run(pcp_grid* g, int mode, double radius, int max_iter, float tol, int full_iter, float* dx_trace,
+                     float* hb_trace, int* iters, int* converged) {
+    if (check_source(g)) return 1;
+    if (max_iter < 1 || max_iter > pcp_grid::max_iter_cap) return pcp_fail("max_iter must be in [1, %d]", pcp_grid::max_iter_cap);
+    PCP_CHECK(hipSetDevice(g->device));
+    hipLaunchKernelGGL(k_map_state, dim3(1), dim3(1), 0, g->stream, g->state, 1);
+    for (int it = 0; it < max_iter; ++it) {
+        if (launch_map_ls(g, mode, radius, false)) return 1;
+        hipLaunchKernelGGL(k_map_finish, dim3(1), dim3(1024), 0, g->stream, map_finish_args(g, g->hb_trace), 1, mode,
+                           max_iter, tol, full_iter);
+    }
+    PCP_CHECK(hipGetLastError());
+    if (pcp_grid_icp_finish(g)) return 1;
+    return pcp_grid_icp_fetch(g, dx_trace, hb_trace, iters, converged, nullptr);
+}
+
+}  // extern "C"

@@ -178,3 +178,37 @@ class PointcloudIcpContainer:
         H, b = self.sumHsBsNumpy(*self.getHsBsNumpy(aligned, to_align))
         delta_x = np.linalg.solve(H, -b)
         return delta_x[:3], delta_x[3:]
+
+    # ------------------------------------------------------------------ legacy exact-NN ICP (:465-515)
+    def getKDTree(self, np_points, cell=None):
+        """:471-472.  The tree is a device cell grid answering the same query()."""
+        from .cell_grid import CellGrid
+        device = self.compute.device if self.compute is not None and hasattr(self.compute, "device") else 0
+        return CellGrid(np_points, cell=cell, device=device)
+
+    def getNearestNeighbours(self, kdTree_pc1, pc1, pc2):
+        """:467-469."""
+        distances, closestIndexes = kdTree_pc1.query(pc2)
+        return np.asarray(pc1)[closestIndexes], pc2, distances
+
+    def icp_step_KD(self, kdTree_pc1, pc1, pc2):
+        """:474-498: exact neighbours, best 80 % by distance, Kabsch.  pc1 is the cloud the
+        grid was built from; the sums run on the device over the resident copy of pc2."""
+        kdTree_pc1.set_source(pc2)
+        return kdTree_pc1.kd_step(0.8)
+
+    def align_KD(self, reference_points, points_to_align, iterations=20):
+        """:500-515, the moving cloud staying on the device between the steps."""
+        tree = self.getKDTree(reference_points)
+        try:
+            tree.set_source(points_to_align)
+            reference_grid = self.getUniformGrid(10)
+            for _ in range(iterations):
+                R, t = tree.kd_step(0.8)
+                tree.apply(R, t)
+                reference_grid = self.applyIcpStep(reference_grid, R, t)
+            moved = tree.read_source()
+        finally:
+            tree.cleanup()
+        R_opt, t_opt = self.uniform_optimal_icp(reference_grid, self.getUniformGrid(10))
+        return moved, R_opt, t_opt

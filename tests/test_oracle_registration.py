@@ -174,3 +174,35 @@ def test_oracle_icp_recovers_a_known_motion():
         t_opt, R_opt = full(a, b, ZERO, iterations=15)
         assert np.abs(R_opt @ R - np.eye(3)).max() < 2e-3
         assert np.abs(R_opt @ t - t_opt).max() < 2e-2
+
+
+# ------------------------------------------------------------------ legacy exact-neighbour ICP
+def test_kd_restatement_equals_reference_step_and_alignment():
+    """np_grid.icp_step_kd / align_kd against the reference's icp_step_KD / align_KD outputs
+    (tests/golden/ref_kd.npz, written by oracle/gen_golden.py from the reference itself)."""
+    from scipy.spatial import KDTree
+    from oracle import np_grid as NG
+    from tests._data import golden, kitti_pair
+    g = golden("ref_kd.npz")
+    a, b = kitti_pair()
+    tree = KDTree(a)
+    dd, ii = tree.query(b[::7])
+    assert np.array_equal(ii, g["kd7_idx"]) and np.array_equal(dd, g["kd7_dist"])
+    R, t = NG.icp_step_kd(tree, a, b)
+    assert np.abs(R - g["step_R"]).max() < 1e-9 and np.abs(t - g["step_t"]).max() < 1e-8
+    d_low, i_low = NG.exact_nn_lowest(a, b[::7])
+    assert np.array_equal(d_low, dd) and np.all(i_low <= ii)
+    same = i_low == ii
+    assert same.mean() > 0.99 and np.array_equal(np.linalg.norm(b[::7][~same] - a[i_low[~same]], axis=1), dd[~same])
+
+
+def test_kd_alignment_restatement_equals_reference():
+    from oracle import np_grid as NG
+    from tests._data import golden, kitti_pair
+    g = golden("ref_kd.npz")
+    a, b = kitti_pair()
+    moved, R_opt, t_opt = NG.align_kd(a[::4], b[::4], iterations=3)      # the restated loop runs
+    assert moved.shape == b[::4].shape and np.abs(R_opt @ R_opt.T - np.eye(3)).max() < 1e-12
+    moved, R_opt, t_opt = NG.align_kd(a, b)
+    assert np.abs(R_opt - g["align_R"]).max() < 1e-7 and np.abs(t_opt - g["align_t"]).max() < 1e-6
+    assert np.abs(moved[::64] - g["align_moved_sub"]).max() < 1e-5
