@@ -43,8 +43,9 @@ int pcp_device_count(int* count);
 int pcp_create(int device, int max_points, int max_scans, pcp_ctx** out);
 /* ComputeShader.cleanup (:966-998). */
 int pcp_destroy(pcp_ctx* ctx);
-/* Run all later work of ctx on an existing hipStream_t (e.g. torch's). NULL
- * restores the context's own stream. */
+/* Run all later work of ctx on an existing hipStream_t (e.g. a torch side
+ * stream). NULL restores the context's own stream; the legacy default stream,
+ * whose handle is NULL, can therefore not be adopted. */
 int pcp_set_stream(pcp_ctx* ctx, void* hip_stream);
 int pcp_synchronize(pcp_ctx* ctx);
 
@@ -206,6 +207,7 @@ typedef struct pcp_grid pcp_grid;
 
 int pcp_grid_create(int device, pcp_grid** out);
 int pcp_grid_destroy(pcp_grid* grid);
+/* As pcp_set_stream. */
 int pcp_grid_set_stream(pcp_grid* grid, void* hip_stream);
 int pcp_grid_synchronize(pcp_grid* grid);
 /* getKDTree (:471-472): index n map points with cubic cells of edge `cell`

@@ -8,4 +8,5 @@ from ._lib import LIB_PATH, PcpError, load  # noqa: F401
 from .alignment import PointcloudAlignment  # noqa: F401
 from .compute_shader import MODE_PLANE, MODE_POINT, ComputeShader, IcpBatch  # noqa: F401
 from .icp_container import PointcloudIcpContainer  # noqa: F401
+from .cell_grid import CellGrid  # noqa: F401
 from .voxelizer import Voxelizer  # noqa: F401

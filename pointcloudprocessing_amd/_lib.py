@@ -95,6 +95,23 @@ SIGNATURES = {
 }
 
 
+def _share_torch_hip_runtime():
+    """PyTorch wheels bundle their own libamdhip64 (soname libamdhip64.so.7, the one libpcp.so asks
+    for).  A process that ends up with two HIP runtimes -- libpcp.so's from /opt/rocm loaded first,
+    torch's afterwards -- finds no GPU in the second one, so when torch is installed its copy is
+    loaded first and serves both."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    path = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(path):
+        C.CDLL(path, mode=C.RTLD_GLOBAL)
+
+
 def load():
     """Loads libpcp.so once; raises PcpError when it has not been built."""
     global _lib
@@ -104,6 +121,7 @@ def load():
         raise PcpError(
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+    _share_torch_hip_runtime()
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError here = header and library disagree
