@@ -259,13 +259,14 @@ int pcp_grid_ls(pcp_grid* grid, int mode, double radius, float* hb);
  * the working copy, leaves the registered cloud there. */
 int pcp_grid_icp_run(pcp_grid* grid, int mode, double radius, int max_iter, float tol, int full_iter,
                      float* dx_trace, float* hb_trace, int* iters, int* converged);
-/* The same loop cut at its one exchange point, for a map split over ranks: each rank
- * holds the map points in or next to its share of the cell-key space and sums only
- * the source points whose cell key k satisfies lo <= k < hi (keys: pcp_grid_cell_keys);
+/* The same loop cut at its one exchange point, for a map split over ranks: space is cut
+ * into partition cells of edge own_cell (>= radius; independent of the grid's own cell),
+ * each rank holds the map points in or next to its share of the partition-cell key space
+ * and sums only the source points whose key k satisfies lo <= k < hi (keys: pcp_grid_cell_keys);
  * the partial 8x8 tiles are all-reduced by the caller between the two calls and every
  * rank solves the same system.  Both calls only enqueue work on the grid's stream;
  * tile_dev is a device buffer of 64 floats. */
-int pcp_grid_set_owned_keys(pcp_grid* grid, unsigned long long lo, unsigned long long hi);
+int pcp_grid_set_owned_keys(pcp_grid* grid, double own_cell, unsigned long long lo, unsigned long long hi);
 int pcp_grid_cell_keys(double cell, const double* xyz, size_t n, unsigned long long* keys);
 int pcp_grid_icp_reset(pcp_grid* grid);
 int pcp_grid_ls_dev(pcp_grid* grid, int mode, double radius, float* tile_dev);

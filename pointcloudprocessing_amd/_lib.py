@@ -73,7 +73,7 @@ SIGNATURES = {
     "pcp_grid_nn_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_longlong), _f64p, C.POINTER(C.c_ubyte)]),
     "pcp_grid_ls": (C.c_int, [C.c_void_p, C.c_int, C.c_double, _f32p]),
     "pcp_grid_icp_run": (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_float, C.c_int, _f32p, _f32p, _i32p, _i32p]),
-    "pcp_grid_set_owned_keys": (C.c_int, [C.c_void_p, C.c_ulonglong, C.c_ulonglong]),
+    "pcp_grid_set_owned_keys": (C.c_int, [C.c_void_p, C.c_double, C.c_ulonglong, C.c_ulonglong]),
     "pcp_grid_cell_keys": (C.c_int, [C.c_double, _f64p, C.c_size_t, C.POINTER(C.c_ulonglong)]),
     "pcp_grid_icp_reset": (C.c_int, [C.c_void_p]),
     "pcp_grid_ls_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_void_p]),

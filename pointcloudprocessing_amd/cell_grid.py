@@ -133,8 +133,11 @@ class CellGrid:
                                          1 if full_iter else 0, f32p(dx), f32p(hb), C.byref(it), C.byref(cv)))
         return dx[:it.value], bool(cv.value), hb[:it.value]
 
-    def set_owned_keys(self, lo, hi):
-        check(self._lib.pcp_grid_set_owned_keys(self._g, int(lo), int(hi)))
+    def set_owned_keys(self, lo, hi, own_cell=None):
+        """Only source points whose partition-cell key (cells of edge own_cell, default the grid's
+        cell) lies in [lo, hi) contribute to ls / icp_run."""
+        check(self._lib.pcp_grid_set_owned_keys(self._g, float(own_cell if own_cell is not None else self.cell),
+                                                int(lo), int(hi)))
 
     def cleanup(self):
         if self._g:

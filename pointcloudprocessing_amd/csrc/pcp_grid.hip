@@ -83,16 +83,20 @@ __device__ __forceinline__ unsigned hash_slot(const unsigned long long key, cons
 // build: cell range, keys, radix sort, hash table, gather
 // ------------------------------------------------------------------------------------------
 
-__global__ void k_cell_range(const double* __restrict__ xyz, size_t n, double cell, int* __restrict__ mm) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+// Grid-stride: every thread folds many points before the wave reduction, so the seven
+// global atomics are issued once per wave of a small fixed grid, not once per 64 points.
+__global__ void __launch_bounds__(256)
+k_cell_range(const double* __restrict__ xyz, size_t n, double cell, int* __restrict__ mm) {
     int lo[3] = {INT_MAX, INT_MAX, INT_MAX}, hi[3] = {INT_MIN, INT_MIN, INT_MIN};
     int bad = 0;
-    if (i < n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
             const double v = xyz[3 * i + a];
             if (!(fabs(v / cell) < (double)(COORD_BIAS - 2))) bad = 1;
-            lo[a] = hi[a] = cell_of(v, cell);
+            const int c = cell_of(v, cell);
+            lo[a] = min(lo[a], c);
+            hi[a] = max(hi[a], c);
         }
     }
 #pragma unroll
@@ -242,11 +246,14 @@ k_rs_scatter(const unsigned long long* __restrict__ keys_in, const unsigned* __r
     }
 }
 
-__global__ void k_count_cells(const unsigned long long* __restrict__ keys, size_t n, unsigned long long* __restrict__ count) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool start = i < n && (i == 0 || keys[i] != keys[i - 1]);
-    const unsigned long long m = __ballot(start);
-    if ((threadIdx.x & 63) == 0 && m) atomicAdd(count, (unsigned long long)__popcll(m));
+__global__ void __launch_bounds__(256)
+k_count_cells(const unsigned long long* __restrict__ keys, size_t n, unsigned long long* __restrict__ count) {
+    unsigned mine = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        mine += (i == 0 || keys[i] != keys[i - 1]) ? 1u : 0u;
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) mine += __shfl_down(mine, s, 64);
+    if ((threadIdx.x & 63) == 0 && mine) atomicAdd(count, (unsigned long long)mine);
 }
 
 __global__ void k_insert_cells(const unsigned long long* __restrict__ keys, size_t n, Cell* __restrict__ table, int log_cap) {
@@ -535,7 +542,7 @@ struct MapLsArgs {
     double* src;
     IcpState* st;
     size_t m;
-    double radius2;
+    double radius2, own_cell;
     unsigned long long own_lo, own_hi;
     float* partials;
     long long* nn_idx;        // optional per-point outputs
@@ -560,9 +567,9 @@ __global__ void __launch_bounds__(PCP_BLOCK) k_map_ls(const MapLsArgs A) {
             px = nx; py = ny; pz = nz;
         }
         if (st->pending) { A.src[3 * i + 0] = px; A.src[3 * i + 1] = py; A.src[3 * i + 2] = pz; }
-        const unsigned long long key = morton3((unsigned)(cell_of(px, A.G.cell) + COORD_BIAS),
-                                               (unsigned)(cell_of(py, A.G.cell) + COORD_BIAS),
-                                               (unsigned)(cell_of(pz, A.G.cell) + COORD_BIAS));
+        const unsigned long long key = morton3((unsigned)(cell_of(px, A.own_cell) + COORD_BIAS),
+                                               (unsigned)(cell_of(py, A.own_cell) + COORD_BIAS),
+                                               (unsigned)(cell_of(pz, A.own_cell) + COORD_BIAS));
         long long bid = -1;
         int bpos = -1;
         double best = A.radius2;
@@ -668,6 +675,7 @@ struct pcp_grid {
     int* mm = nullptr;
     unsigned long long* cell_count = nullptr;
     unsigned long long own_lo = 0, own_hi = 1ull << 63;
+    double own_cell = 1.0;
     bool nn_valid = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
     static const int max_iter_cap = 1024;
@@ -732,7 +740,7 @@ MapLsArgs map_args(pcp_grid* g, double radius, bool per_point) {
     A.normals = g->normals;
     A.src = g->src; A.st = g->state; A.m = g->m;
     A.radius2 = radius * radius;
-    A.own_lo = g->own_lo; A.own_hi = g->own_hi;
+    A.own_lo = g->own_lo; A.own_hi = g->own_hi; A.own_cell = g->own_cell;
     A.partials = g->partials;
     A.nn_idx = per_point ? g->nn_idx : nullptr;
     A.nn_d = per_point ? g->nn_d : nullptr;
@@ -866,7 +874,7 @@ int pcp_grid_build(pcp_grid* g, const double* xyz, size_t n, double cell, const 
     // cell range
     const int init[8] = {INT_MAX, INT_MAX, INT_MAX, INT_MIN, INT_MIN, INT_MIN, 0, 0};
     GRID_TRY(hipMemcpyAsync(g->mm, init, sizeof(init), hipMemcpyHostToDevice, s));
-    hipLaunchKernelGGL(k_cell_range, dim3(blocks_for(n, 256)), dim3(256), 0, s, d_xyz, n, cell, g->mm);
+    hipLaunchKernelGGL(k_cell_range, dim3(std::min<unsigned>(blocks_for(n, 256), 2048)), dim3(256), 0, s, d_xyz, n, cell, g->mm);
     int mm[8];
     GRID_TRY(hipMemcpyAsync(mm, g->mm, sizeof(mm), hipMemcpyDeviceToHost, s));
     GRID_TRY(hipStreamSynchronize(s));
@@ -908,7 +916,7 @@ int pcp_grid_build(pcp_grid* g, const double* xyz, size_t n, double cell, const 
     GRID_TRY(hipGetLastError());
     // occupied cells -> hash table
     GRID_TRY(hipMemsetAsync(g->cell_count, 0, 8, s));
-    hipLaunchKernelGGL(k_count_cells, dim3(blocks_for(n, 256)), dim3(256), 0, s, kin, n, g->cell_count);
+    hipLaunchKernelGGL(k_count_cells, dim3(std::min<unsigned>(blocks_for(n, 256), 2048)), dim3(256), 0, s, kin, n, g->cell_count);
     unsigned long long cells = 0;
     GRID_TRY(hipMemcpyAsync(&cells, g->cell_count, 8, hipMemcpyDeviceToHost, s));
     GRID_TRY(hipStreamSynchronize(s));
@@ -1084,9 +1092,11 @@ int pcp_grid_nn_read(pcp_grid* g, long long* idx, double* dist, unsigned char* s
     return 0;
 }
 
-int pcp_grid_set_owned_keys(pcp_grid* g, unsigned long long lo, unsigned long long hi) {
+int pcp_grid_set_owned_keys(pcp_grid* g, double own_cell, unsigned long long lo, unsigned long long hi) {
     if (!g) return pcp_fail("null grid");
     if (lo > hi) return pcp_fail("owned key range is empty");
+    if (!(own_cell > 0.0)) return pcp_fail("partition cell size must be positive");
+    g->own_cell = own_cell;
     g->own_lo = lo;
     g->own_hi = hi;
     return 0;

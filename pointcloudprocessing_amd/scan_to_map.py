@@ -88,12 +88,14 @@ class HipMapBackend:
         self.tile = None
         self.stream = None
 
-    def build(self, points, normals, cell):
+    def build(self, points, normals, cell, nn_cell=None):
         torch = self._torch
+        self.own_cell = float(cell)
+        nn_cell = float(nn_cell) if nn_cell else self.own_cell
         if self.grid is None:
-            self.grid = self._CellGrid(points, cell=cell, normals=normals, device=self.device)
+            self.grid = self._CellGrid(points, cell=nn_cell, normals=normals, device=self.device)
         else:
-            self.grid.rebuild(points, cell=cell, normals=normals)
+            self.grid.rebuild(points, cell=nn_cell, normals=normals)
         dev = torch.device("cuda", self.device)
         self.tile = torch.zeros(64, dtype=torch.float32, device=dev)
         # kernels and collective are ordered by one stream: a torch side stream that the grid adopts
@@ -107,7 +109,7 @@ class HipMapBackend:
         return self._torch.cuda.stream(self.stream)
 
     def set_owned(self, lo, hi):
-        self.grid.set_owned_keys(lo, hi)
+        self.grid.set_owned_keys(lo, hi, self.own_cell)
 
     def set_source(self, scan):
         self.grid.set_source(scan)
@@ -153,7 +155,11 @@ class MapRegistration:
     register() with the same scan.  backend: an object with HipMapBackend's methods (tests inject a
     CPU checker); group: a torch.distributed process group, None = the default one when world > 1."""
 
-    def __init__(self, map_points, cell, normals=None, rank=0, world=1, device=0, backend=None, group=None):
+    def __init__(self, map_points, cell, normals=None, rank=0, world=1, device=0, backend=None, group=None,
+                 nn_cell=None):
+        """cell: edge of the partition cells (ownership and halo; the search radius may not exceed it).
+        nn_cell: edge of the search grid's cells on each rank (default: cell); dense maps want it
+        smaller, a few point spacings."""
         self.rank, self.world, self.cell = int(rank), int(world), float(cell)
         self.group = group
         self.backend = backend if backend is not None else HipMapBackend(device)
@@ -165,7 +171,10 @@ class MapRegistration:
             pts = pts[keep]
             normals = None if normals is None else np.asarray(normals)[keep]
         self.slab_points = len(pts)
-        self.backend.build(pts, normals, self.cell)
+        if nn_cell is None:
+            self.backend.build(pts, normals, self.cell)
+        else:
+            self.backend.build(pts, normals, self.cell, nn_cell)
         self.backend.set_owned(lo, hi)
 
     def _all_reduce(self, tile):

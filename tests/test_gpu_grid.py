@@ -310,7 +310,7 @@ rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 torch.cuda.set_device(0)
 dist.init_process_group("gloo")
 pts, nrm, src = _map_scene()
-reg = S.MapRegistration(pts, 0.5, normals=nrm, rank=rank, world=world, device=0)
+reg = S.MapRegistration(pts, 0.5, normals=nrm, rank=rank, world=world, device=0, nn_cell=0.2)
 out = {"slab": reg.slab_points}
 for mode in (0, 1):
     t_opt, R_opt, dx, conv = reg.register(src, mode, 0.4, max_iter=8)

@@ -1,0 +1,39 @@
+"""Cell-grid leg (BASELINE configs[2]): 1M-point clouds, cell sizes 0.1-2.0 m: build (Morton radix
+sort + cell hash) and exact self-query with 5 cm jitter.  Prints one line per case.
+    python tools/bench_grid.py [n_points]"""
+import sys
+import os
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from pointcloudprocessing_amd import lidar  # noqa: E402
+from pointcloudprocessing_amd.cell_grid import CellGrid  # noqa: E402
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
+rng = np.random.default_rng(1)
+clouds = {}
+if n <= 4_000_000:
+    clouds["lidar-like (64 rings x %d steps)" % (n // 64)] = lidar.synthetic_scan(3, rings=65, steps=n // 64 + 1)[:n]
+side = 80.0 * max(1.0, (n / 1e6) ** 0.5)
+clouds["uniform box %.0fx10x%.0f m" % (2 * side, 2 * side)] = rng.uniform([-side, -7, -side], [side, 3, side], (n, 3))
+for name, cloud in clouds.items():
+    q = cloud[:min(len(cloud), 4_000_000)] + rng.normal(0, 0.05, (min(len(cloud), 4_000_000), 3))
+    print(f"== {name}: {len(cloud)} points")
+    g = None
+    for cell in (0.1, 0.2, 0.5, 1.0, 2.0):
+        t0 = time.perf_counter()
+        if g is None:
+            g = CellGrid(cloud, cell=cell)
+        else:
+            g.rebuild(cloud, cell=cell)
+        wall = (time.perf_counter() - t0) * 1e3
+        info = g.info()
+        g.query(q)                                          # warm
+        best = min(g.query(return_kernel_ms=True)[2] for _ in range(3))
+        sort_gbs = 24.0 * len(cloud) * info["sort_passes"] / (info["sort_ms"] * 1e-3) / 1e9 if info["sort_ms"] else 0
+        print(f"cell {cell:4.1f} m: cells {info['cells']:8d}  build {info['build_ms']:7.2f} ms (wall incl. upload {wall:7.1f})  "
+              f"sort {info['sort_ms']:6.3f} ms x{info['sort_passes']} = {sort_gbs:7.1f} GB/s   "
+              f"query {best:8.3f} ms = {len(q) / best / 1e3:8.1f} M/s = {32.0 * len(q) / best / 1e6:7.1f} GB/s alg")
+    g.cleanup()
