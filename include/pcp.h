@@ -57,6 +57,10 @@ int pcp_synchronize(pcp_ctx* ctx);
  * unit-sphere projection of every target point (FunctionalBase.glsl:41-48). */
 int pcp_set_target(pcp_ctx* ctx, const float* a_xyzw, int n_a,
                    const uint32_t* scan_lines, int n_scans, const float* origin4);
+/* The same with the target cloud already in device memory (e.g. pcp_frame_padded_dev);
+ * scan lines and origin stay host pointers. */
+int pcp_set_target_dev(pcp_ctx* ctx, const float* a_xyzw_dev, int n_a,
+                       const uint32_t* scan_lines, int n_scans, const float* origin4);
 /* setInitialScanGuess (:488-489) alone. */
 int pcp_reset_hints(pcp_ctx* ctx);
 
@@ -274,6 +278,35 @@ int pcp_grid_pose_dev(pcp_grid* grid, const float* tile_dev, int mode, int max_i
 /* Applies the step still pending after the last pcp_grid_pose_dev. */
 int pcp_grid_icp_finish(pcp_grid* grid);
 int pcp_grid_icp_fetch(pcp_grid* grid, float* dx_trace, float* hb_trace, int* iters, int* converged, int* done);
+
+/* ---------------------------------------------------------------------------
+ * Frame preparation on the device: KITTI decode + ego filter + axis rotation
+ * (LidarDataReader.eatBytes :144-150, :59-61, :66-67), the IMU pre-alignment
+ * (EnvironmentConstructor.py:169, :209) and the ring segmentation
+ * (PointcloudIcpContainer.getScanLines :362-392), so that a frame goes from the
+ * file's bytes to the registration kernels without host-side array passes.
+ * ------------------------------------------------------------------------- */
+typedef struct pcp_frame pcp_frame;
+
+int pcp_frame_create(int device, size_t max_points, pcp_frame** out);
+int pcp_frame_destroy(pcp_frame* frame);
+/* raw_xyzi: n float32 rows (x, y, z, intensity) as stored in a velodyne .bin.  Keeps the
+ * rows with float32 |(x,y,z)| > min_range in file order, rotates them by R9 (row-major
+ * float64 3x3) into the resident float64 cloud; n_out = rows kept. */
+int pcp_frame_decode(pcp_frame* frame, const float* raw_xyzi, size_t n, float min_range, const double* R9,
+                     size_t* n_out);
+/* Make an existing float64 cloud the resident one. */
+int pcp_frame_upload(pcp_frame* frame, const double* xyz, size_t n);
+/* p <- R p + t on the resident cloud. */
+int pcp_frame_move(pcp_frame* frame, const double* R9, const double* t3);
+/* getScanLines on the resident cloud: lines receives (begin, end_inclusive) pairs. */
+int pcp_frame_scan_lines(pcp_frame* frame, const double* origin3, int max_lines, uint32_t* lines, int* n_lines);
+int pcp_frame_read(pcp_frame* frame, double* xyz, float* intensity);
+/* Device views of the resident cloud: float64 xyz (for pcp_upload_source_dev) and its
+ * float32 padded copy (pad_points + cast, ComputeShader.py:956-961, :301-316; for
+ * pcp_set_target_dev).  Valid until the next call that changes the frame. */
+int pcp_frame_points_dev(pcp_frame* frame, const double** xyz_dev, size_t* n);
+int pcp_frame_padded_dev(pcp_frame* frame, const float** xyzw_dev, size_t* n);
 
 #ifdef __cplusplus
 }

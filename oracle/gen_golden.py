@@ -8,6 +8,7 @@ Needs /root/reference (read-only).  Three kinds of vectors:
                    (PointcloudIcpContainer, PointcloudAlignment), the known
                    answers that pin the restatement in oracle/np_oracle.py
   ref_voxel.npz    the reference's own Voxelizer (CPU path) on the two KITTI frames
+  ref_imu.npz      the reference's odometry driver in IMU-only mode over the sample OXTS records
   ref_kd.npz       the reference's legacy KD-tree ICP (icp_step_KD, align_KD) on the pair
   oracle_kitti.npz outputs of oracle/np_oracle.py on the KITTI pair (full-size
                    parity targets for the HIP kernels, so GPU tests need not
@@ -165,6 +166,58 @@ def ref_kd(frames):
     np.savez_compressed(os.path.join(OUT, "ref_kd.npz"), **out)
 
 
+def ref_imu():
+    """The reference's odometry driver in its IMU-only mode (EnvironmentConstructor.calculateTransition_imu
+    with pure_imu=True, :154-265) over the OXTS records of sample_data, with a 40-point stand-in cloud per
+    frame: pins the IMU prediction, the pre-alignment of the points and the pose bookkeeping.  The
+    records themselves are stored so that the test needs no KITTI files."""
+    import types
+    sys.path.insert(0, REF)
+    for name in ("Renderer", "VoxelManager"):
+        if name not in sys.modules:
+            m = types.ModuleType(name)
+            setattr(m, name, type(name, (), {"__init__": lambda self, *a, **k: None}))
+            sys.modules[name] = m
+    from EnvironmentConstructor import EnvironmentConstructor
+    from OXTS import OXTS
+    from OxtsDataReader import OxtsDataReader
+    root = os.path.join(REF, "sample_data")
+    rd = OxtsDataReader()
+    stamps = rd.readTimestamps(os.path.join(root, "oxts", "timestamps.txt"))
+    lines = open(os.path.join(root, "oxts", "timestamps.txt")).read().splitlines()
+    names = sorted(n for n in os.listdir(os.path.join(root, "oxts", "data")) if n.endswith(".txt"))
+    values = np.stack([np.array(open(os.path.join(root, "oxts", "data", n)).readline().split(), dtype=np.float64)
+                       for n in names])
+
+    class Sink:
+        def __init__(self):
+            self.clouds = []
+        def init(self, voxel_size):
+            pass
+        def addPoints(self, points, colors):
+            self.clouds.append(np.array(points))
+        def cleanup(self):
+            pass
+
+    class Paint:
+        def addPoints(self, *a, **k):
+            return None
+
+    env = EnvironmentConstructor(Paint(), None, None, None, None)
+    env.voxelizer = Sink()
+    env.framekeys, env.frameindex, env.local_frame_counter, env.total_frame_counter, env.prev_poses = [], 0, 0, 0, []
+    rng = np.random.default_rng(12)
+    cloud = rng.uniform(-30, 30, (40, 3))
+    for k in range(len(names)):
+        ox = OXTS(*values[k], stamps[k])
+        env.calculateTransition_imu((cloud.copy(), None, np.zeros((40, 3))), ox, pure_imu=True)
+    out = dict(oxts_values=values, oxts_stamps=np.array(lines[:len(names)]), cloud=cloud,
+               imu_pos=np.stack([p[0] for p in env.prev_poses]), refined_pos=np.stack([p[1] for p in env.prev_poses]),
+               rotation=np.stack([p[2] for p in env.prev_poses]), moved=np.stack(env.voxelizer.clouds),
+               true_rot0=ox.getTrueRotation(np.eye(3)), yaw_rot0=ox.getYawRotation(np.eye(3)), velocity0=ox.getVelocity())
+    np.savez_compressed(os.path.join(OUT, "ref_imu.npz"), **out)
+
+
 def oracle_kitti(frames):
     from oracle import np_oracle as O
     A, B = frames
@@ -201,6 +254,8 @@ if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     raw = kitti_pair()
     frames = ref_kat(raw)
+    if "--no-imu" not in sys.argv:
+        ref_imu()
     if "--no-kd" not in sys.argv:
         ref_kd(frames)
     if "--no-voxel" not in sys.argv:

@@ -9,4 +9,7 @@ from .alignment import PointcloudAlignment  # noqa: F401
 from .compute_shader import MODE_PLANE, MODE_POINT, ComputeShader, IcpBatch  # noqa: F401
 from .icp_container import PointcloudIcpContainer  # noqa: F401
 from .cell_grid import CellGrid  # noqa: F401
+from .environment import EnvironmentConstructor  # noqa: F401
+from .frame import DeviceFrame  # noqa: F401
+from .oxts import OXTS, OxtsDataReader  # noqa: F401
 from .voxelizer import Voxelizer  # noqa: F401

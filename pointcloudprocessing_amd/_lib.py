@@ -80,6 +80,16 @@ SIGNATURES = {
     "pcp_grid_pose_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_int]),
     "pcp_grid_icp_finish": (C.c_int, [C.c_void_p]),
     "pcp_grid_icp_fetch": (C.c_int, [C.c_void_p, _f32p, _f32p, _i32p, _i32p, _i32p]),
+    "pcp_set_target_dev": (C.c_int, [_ctx, C.c_void_p, C.c_int, _u32p, C.c_int, _f32p]),
+    "pcp_frame_create": (C.c_int, [C.c_int, C.c_size_t, C.POINTER(C.c_void_p)]),
+    "pcp_frame_destroy": (C.c_int, [C.c_void_p]),
+    "pcp_frame_decode": (C.c_int, [C.c_void_p, _f32p, C.c_size_t, C.c_float, _f64p, C.POINTER(C.c_size_t)]),
+    "pcp_frame_upload": (C.c_int, [C.c_void_p, _f64p, C.c_size_t]),
+    "pcp_frame_move": (C.c_int, [C.c_void_p, _f64p, _f64p]),
+    "pcp_frame_scan_lines": (C.c_int, [C.c_void_p, _f64p, C.c_int, _u32p, _i32p]),
+    "pcp_frame_read": (C.c_int, [C.c_void_p, _f64p, _f32p]),
+    "pcp_frame_points_dev": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
+    "pcp_frame_padded_dev": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
     "pcp_batch_create": (C.c_int, [C.POINTER(_ctx), C.c_int, C.POINTER(C.c_void_p)]),
     "pcp_batch_destroy": (C.c_int, [C.c_void_p]),
     "pcp_batch_prepare": (C.c_int, [C.c_void_p, C.c_int]),

@@ -1,0 +1,330 @@
+// Frame preparation on the device: the numeric steps between a KITTI velodyne
+// file and the registration kernels.
+//   decode   LidarDataReader.eatBytes (LidarDataReader.py:144-150), the ego filter
+//            |p| > 2.5 m in float32 (:59-61) and the axis-aligning rotation in
+//            float64 (:66-67), as one ordered stream compaction
+//   move     (R @ p.T).T + t, the IMU pre-alignment of a frame
+//            (EnvironmentConstructor.py:169, :209)
+//   rings    PointcloudIcpContainer.getScanLines (:362-392): azimuth of the
+//            unit-sphere projection about origin + (0, 0.127, 0), a ring ends where
+//            |azimuth[i+1] - azimuth[i]| > 6; points after the last wrap belong to no ring
+// Buffers: raw float4[cap] (x, y, z, intensity), xyz double[3 cap], intensity
+// float[cap], ends uint32[cap], block counts uint32[cap / 2048 + 1].
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "../../include/pcp.h"
+#include "pcp_host.h"
+
+namespace {
+
+constexpr int FR_THREADS = 256;
+constexpr int FR_ITEMS = 8;
+constexpr int FR_TILE = FR_THREADS * FR_ITEMS;
+
+struct KeepFar {          // ego filter: np.linalg.norm(float32 rows) > min_range
+    const float4* raw;
+    float min_range;
+    __device__ bool operator()(size_t i) const {
+        const float4 p = raw[i];
+        const float s = (p.x * p.x + p.y * p.y) + p.z * p.z;
+        return sqrtf(s) > min_range;
+    }
+};
+
+struct Wrap {             // ring boundary after point i
+    const double* xyz;
+    double ox, oy, oz;
+    __device__ double azimuth(size_t i) const {
+        const double vx = xyz[3 * i + 0] - ox, vy = (xyz[3 * i + 1] - oy) - 0.127, vz = xyz[3 * i + 2] - oz;
+        const double mag = sqrt((vx * vx + vy * vy) + vz * vz);
+        double a = atan2(vz / mag, vx / mag);
+        if (a < 0.0) a += 6.283185307179586;        // np.pi * 2
+        return a;
+    }
+    __device__ bool operator()(size_t i) const { return fabs(azimuth(i + 1) - azimuth(i)) > 6.0; }
+};
+
+template <class Pred>
+__global__ void __launch_bounds__(FR_THREADS) k_count(const Pred pred, size_t n, unsigned* __restrict__ counts) {
+    __shared__ unsigned total;
+    if (threadIdx.x == 0) total = 0;
+    __syncthreads();
+    const size_t base = (size_t)blockIdx.x * FR_TILE;
+    unsigned mine = 0;
+#pragma unroll
+    for (int k = 0; k < FR_ITEMS; ++k) {
+        const size_t i = base + (size_t)k * FR_THREADS + threadIdx.x;
+        if (i < n && pred(i)) ++mine;
+    }
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) mine += __shfl_down(mine, s, 64);
+    if ((threadIdx.x & 63) == 0) atomicAdd(&total, mine);
+    __syncthreads();
+    if (threadIdx.x == 0) counts[blockIdx.x] = total;
+}
+
+// Exclusive prefix of counts[0..nblk) in place; the grand total goes to counts[nblk].
+__global__ void __launch_bounds__(1024) k_scan_counts(unsigned* __restrict__ counts, int nblk) {
+    __shared__ unsigned s[1024];
+    __shared__ unsigned run;
+    if (threadIdx.x == 0) run = 0;
+    __syncthreads();
+    for (int base = 0; base < nblk; base += 1024) {
+        const int i = base + threadIdx.x;
+        const unsigned v = (i < nblk) ? counts[i] : 0u;
+        s[threadIdx.x] = v;
+        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1) {
+            const unsigned t = (threadIdx.x >= (unsigned)off) ? s[threadIdx.x - off] : 0u;
+            __syncthreads();
+            s[threadIdx.x] += t;
+            __syncthreads();
+        }
+        if (i < nblk) counts[i] = run + s[threadIdx.x] - v;
+        __syncthreads();
+        if (threadIdx.x == 0) run += s[1023];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) counts[nblk] = run;
+}
+
+// Ordered scatter: element i (in index order) with pred(i) goes to slot
+// offsets[block] + its rank inside the block; emit(i, slot) writes it.
+template <class Pred, class Emit>
+__global__ void __launch_bounds__(FR_THREADS)
+k_scatter(const Pred pred, const Emit emit, size_t n, const unsigned* __restrict__ offsets) {
+    __shared__ unsigned wave_total[FR_THREADS / 64];
+    __shared__ unsigned running;
+    if (threadIdx.x == 0) running = offsets[blockIdx.x];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const size_t base = (size_t)blockIdx.x * FR_TILE;
+    for (int k = 0; k < FR_ITEMS; ++k) {
+        const size_t i = base + (size_t)k * FR_THREADS + threadIdx.x;
+        const bool keep = i < n && pred(i);
+        const unsigned long long bal = __ballot(keep);
+        if (lane == 0) wave_total[w] = (unsigned)__popcll(bal);
+        __syncthreads();
+        unsigned before = running, all = 0;
+        for (int j = 0; j < FR_THREADS / 64; ++j) { if (j < w) before += wave_total[j]; all += wave_total[j]; }
+        if (keep) emit(i, (size_t)before + (unsigned)__popcll(bal & ((1ull << lane) - 1ull)));
+        __syncthreads();
+        if (threadIdx.x == 0) running += all;
+        __syncthreads();
+    }
+}
+
+struct EmitDecoded {      // rotated float64 point + intensity
+    const float4* raw;
+    double R[9];
+    double* xyz;
+    float* intensity;
+    __device__ void operator()(size_t i, size_t slot) const {
+        const float4 p = raw[i];
+        const double x = (double)p.x, y = (double)p.y, z = (double)p.z;
+        // one fused chain per row, the order of the float64 GEMM kernel NumPy's matmul runs on x86-64
+        // (checked against the reference's frames: two points of KITTI frame 0 tell the orders apart)
+        xyz[3 * slot + 0] = fma(R[2], z, fma(R[1], y, R[0] * x));
+        xyz[3 * slot + 1] = fma(R[5], z, fma(R[4], y, R[3] * x));
+        xyz[3 * slot + 2] = fma(R[8], z, fma(R[7], y, R[6] * x));
+        intensity[slot] = p.w;
+    }
+};
+
+struct EmitIndex {
+    unsigned* out;
+    __device__ void operator()(size_t i, size_t slot) const { out[slot] = (unsigned)i; }
+};
+
+__global__ void k_move(double* __restrict__ xyz, size_t n, const double* __restrict__ Rt) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double x = xyz[3 * i + 0], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
+    xyz[3 * i + 0] = fma(Rt[2], z, fma(Rt[1], y, Rt[0] * x)) + Rt[9];
+    xyz[3 * i + 1] = fma(Rt[5], z, fma(Rt[4], y, Rt[3] * x)) + Rt[10];
+    xyz[3 * i + 2] = fma(Rt[8], z, fma(Rt[7], y, Rt[6] * x)) + Rt[11];
+}
+
+// ComputeShader.pad_points (:956-961) + the float32 cast of the upload (:301-316).
+__global__ void k_pad32(const double* __restrict__ xyz, size_t n, float4* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    out[i] = make_float4((float)xyz[3 * i + 0], (float)xyz[3 * i + 1], (float)xyz[3 * i + 2], 0.0f);
+}
+
+inline unsigned blocks_for(size_t n, int threads) { return (unsigned)((n + threads - 1) / threads); }
+
+}  // namespace
+
+struct pcp_frame {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    size_t cap = 0, n = 0;
+    float4* raw = nullptr;
+    double* xyz = nullptr;
+    float* intensity = nullptr;
+    float4* xyzw32 = nullptr;
+    unsigned *ends = nullptr, *counts = nullptr;
+    double* rt = nullptr;
+};
+
+extern "C" {
+
+int pcp_frame_create(int device, size_t max_points, pcp_frame** out) {
+    if (!out) return pcp_fail("out is null");
+    *out = nullptr;
+    if (max_points == 0 || max_points >= (1ull << 31)) return pcp_fail("max_points must be in [1, 2^31)");
+    int count = 0;
+    PCP_CHECK(hipGetDeviceCount(&count));
+    if (device < 0 || device >= count) return pcp_fail("device %d out of range (%d devices)", device, count);
+    PCP_CHECK(hipSetDevice(device));
+    pcp_frame* f = new pcp_frame();
+    f->device = device;
+    f->cap = max_points;
+    PCP_CHECK(hipStreamCreateWithFlags(&f->stream, hipStreamNonBlocking));
+    PCP_CHECK(hipMalloc(&f->raw, max_points * 16));
+    PCP_CHECK(hipMalloc(&f->xyz, max_points * 24));
+    PCP_CHECK(hipMalloc(&f->intensity, max_points * 4));
+    PCP_CHECK(hipMalloc(&f->xyzw32, max_points * 16));
+    PCP_CHECK(hipMalloc(&f->ends, max_points * 4));
+    PCP_CHECK(hipMalloc(&f->counts, (max_points / FR_TILE + 2) * 4));
+    PCP_CHECK(hipMalloc(&f->rt, 12 * 8));
+    *out = f;
+    return 0;
+}
+
+int pcp_frame_destroy(pcp_frame* f) {
+    if (!f) return 0;
+    PCP_CHECK(hipSetDevice(f->device));
+    PCP_CHECK(hipStreamSynchronize(f->stream));
+    for (void* p : {(void*)f->raw, (void*)f->xyz, (void*)f->intensity, (void*)f->xyzw32, (void*)f->ends,
+                    (void*)f->counts, (void*)f->rt})
+        if (p) PCP_CHECK(hipFree(p));
+    PCP_CHECK(hipStreamDestroy(f->stream));
+    delete f;
+    return 0;
+}
+
+int pcp_frame_decode(pcp_frame* f, const float* raw_xyzi, size_t n, float min_range, const double* R9, size_t* n_out) {
+    if (!f) return pcp_fail("null frame");
+    if (n > f->cap) return pcp_fail("%zu raw points exceed the frame capacity %zu", n, f->cap);
+    if (n && !raw_xyzi) return pcp_fail("raw_xyzi is null");
+    if (!R9) return pcp_fail("R9 is null");
+    PCP_CHECK(hipSetDevice(f->device));
+    f->n = 0;
+    if (n_out) *n_out = 0;
+    if (n == 0) return 0;
+    PCP_CHECK(hipMemcpyAsync(f->raw, raw_xyzi, n * 16, hipMemcpyHostToDevice, f->stream));
+    const int nblk = (int)((n + FR_TILE - 1) / FR_TILE);
+    const KeepFar pred{f->raw, min_range};
+    EmitDecoded emit;
+    emit.raw = f->raw;
+    memcpy(emit.R, R9, sizeof(emit.R));
+    emit.xyz = f->xyz;
+    emit.intensity = f->intensity;
+    hipLaunchKernelGGL(k_count<KeepFar>, dim3(nblk), dim3(FR_THREADS), 0, f->stream, pred, n, f->counts);
+    hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, f->stream, f->counts, nblk);
+    hipLaunchKernelGGL((k_scatter<KeepFar, EmitDecoded>), dim3(nblk), dim3(FR_THREADS), 0, f->stream, pred, emit, n, f->counts);
+    PCP_CHECK(hipGetLastError());
+    unsigned kept = 0;
+    PCP_CHECK(hipMemcpyAsync(&kept, f->counts + nblk, 4, hipMemcpyDeviceToHost, f->stream));
+    PCP_CHECK(hipStreamSynchronize(f->stream));
+    f->n = kept;
+    if (n_out) *n_out = kept;
+    return 0;
+}
+
+int pcp_frame_upload(pcp_frame* f, const double* xyz, size_t n) {
+    if (!f) return pcp_fail("null frame");
+    if (n > f->cap) return pcp_fail("%zu points exceed the frame capacity %zu", n, f->cap);
+    if (n && !xyz) return pcp_fail("xyz is null");
+    PCP_CHECK(hipSetDevice(f->device));
+    if (n) PCP_CHECK(hipMemcpyAsync(f->xyz, xyz, n * 24, hipMemcpyHostToDevice, f->stream));
+    PCP_CHECK(hipStreamSynchronize(f->stream));
+    f->n = n;
+    return 0;
+}
+
+int pcp_frame_move(pcp_frame* f, const double* R9, const double* t3) {
+    if (!f) return pcp_fail("null frame");
+    if (!R9 || !t3) return pcp_fail("R or t is null");
+    PCP_CHECK(hipSetDevice(f->device));
+    if (f->n == 0) return 0;
+    double rt[12];
+    memcpy(rt, R9, 72);
+    memcpy(rt + 9, t3, 24);
+    PCP_CHECK(hipStreamSynchronize(f->stream));
+    PCP_CHECK(hipMemcpyAsync(f->rt, rt, sizeof(rt), hipMemcpyHostToDevice, f->stream));
+    hipLaunchKernelGGL(k_move, dim3(blocks_for(f->n, 256)), dim3(256), 0, f->stream, f->xyz, f->n, f->rt);
+    PCP_CHECK(hipGetLastError());
+    PCP_CHECK(hipStreamSynchronize(f->stream));
+    return 0;
+}
+
+int pcp_frame_scan_lines(pcp_frame* f, const double* origin3, int max_lines, uint32_t* lines, int* n_lines) {
+    if (!f) return pcp_fail("null frame");
+    if (!origin3 || !lines || !n_lines) return pcp_fail("origin3, lines or n_lines is null");
+    PCP_CHECK(hipSetDevice(f->device));
+    *n_lines = 0;
+    if (f->n < 2) return 0;
+    const size_t m = f->n - 1;
+    const int nblk = (int)((m + FR_TILE - 1) / FR_TILE);
+    const Wrap pred{f->xyz, origin3[0], origin3[1], origin3[2]};
+    const EmitIndex emit{f->ends};
+    hipLaunchKernelGGL(k_count<Wrap>, dim3(nblk), dim3(FR_THREADS), 0, f->stream, pred, m, f->counts);
+    hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, f->stream, f->counts, nblk);
+    hipLaunchKernelGGL((k_scatter<Wrap, EmitIndex>), dim3(nblk), dim3(FR_THREADS), 0, f->stream, pred, emit, m, f->counts);
+    PCP_CHECK(hipGetLastError());
+    unsigned found = 0;
+    PCP_CHECK(hipMemcpyAsync(&found, f->counts + nblk, 4, hipMemcpyDeviceToHost, f->stream));
+    PCP_CHECK(hipStreamSynchronize(f->stream));
+    if ((long long)found > (long long)max_lines)
+        return pcp_fail("%u scan lines found, room for %d", found, max_lines);
+    std::vector<unsigned> ends(found);
+    if (found) PCP_CHECK(hipMemcpy(ends.data(), f->ends, (size_t)found * 4, hipMemcpyDeviceToHost));
+    unsigned begin = 0;
+    for (unsigned k = 0; k < found; ++k) {
+        lines[2 * k + 0] = begin;
+        lines[2 * k + 1] = ends[k];
+        begin = ends[k] + 1;
+    }
+    *n_lines = (int)found;
+    return 0;
+}
+
+int pcp_frame_read(pcp_frame* f, double* xyz, float* intensity) {
+    if (!f) return pcp_fail("null frame");
+    PCP_CHECK(hipSetDevice(f->device));
+    if (f->n && xyz) PCP_CHECK(hipMemcpyAsync(xyz, f->xyz, f->n * 24, hipMemcpyDeviceToHost, f->stream));
+    if (f->n && intensity) PCP_CHECK(hipMemcpyAsync(intensity, f->intensity, f->n * 4, hipMemcpyDeviceToHost, f->stream));
+    PCP_CHECK(hipStreamSynchronize(f->stream));
+    return 0;
+}
+
+int pcp_frame_points_dev(pcp_frame* f, const double** xyz_dev, size_t* n) {
+    if (!f) return pcp_fail("null frame");
+    if (xyz_dev) *xyz_dev = f->xyz;
+    if (n) *n = f->n;
+    return 0;
+}
+
+int pcp_frame_padded_dev(pcp_frame* f, const float** xyzw_dev, size_t* n) {
+    if (!f) return pcp_fail("null frame");
+    PCP_CHECK(hipSetDevice(f->device));
+    if (f->n) {
+        hipLaunchKernelGGL(k_pad32, dim3(blocks_for(f->n, 256)), dim3(256), 0, f->stream, f->xyz, f->n, f->xyzw32);
+        PCP_CHECK(hipGetLastError());
+        PCP_CHECK(hipStreamSynchronize(f->stream));
+    }
+    if (xyzw_dev) *xyzw_dev = reinterpret_cast<const float*>(f->xyzw32);
+    if (n) *n = f->n;
+    return 0;
+}
+
+}  // extern "C"

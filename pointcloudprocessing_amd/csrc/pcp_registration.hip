@@ -613,8 +613,21 @@ int pcp_prepare_resident(pcp_ctx* c, int with_normals) {
     return 0;
 }
 
+static int set_target_impl(pcp_ctx* c, const float* a_xyzw, int n_a, const uint32_t* scan_lines, int n_scans,
+                           const float* origin4, hipMemcpyKind kind);
+
 int pcp_set_target(pcp_ctx* c, const float* a_xyzw, int n_a, const uint32_t* scan_lines, int n_scans,
                    const float* origin4) {
+    return set_target_impl(c, a_xyzw, n_a, scan_lines, n_scans, origin4, hipMemcpyHostToDevice);
+}
+
+int pcp_set_target_dev(pcp_ctx* c, const float* a_xyzw_dev, int n_a, const uint32_t* scan_lines, int n_scans,
+                       const float* origin4) {
+    return set_target_impl(c, a_xyzw_dev, n_a, scan_lines, n_scans, origin4, hipMemcpyDeviceToDevice);
+}
+
+static int set_target_impl(pcp_ctx* c, const float* a_xyzw, int n_a, const uint32_t* scan_lines, int n_scans,
+                           const float* origin4, hipMemcpyKind kind) {
     if (int e = use(c)) return e;
     if (!a_xyzw || !scan_lines || !origin4) return pcp_fail("null argument");
     if (n_a < 1 || n_a > c->max_points) return pcp_fail("n_a = %d outside [1, %d]", n_a, c->max_points);
@@ -630,7 +643,7 @@ int pcp_set_target(pcp_ctx* c, const float* a_xyzw, int n_a, const uint32_t* sca
     }
     c->have_target = false;
     c->have_normals = false;
-    PCP_CHECK(hipMemcpyAsync(c->a, a_xyzw, (size_t)n_a * sizeof(float4), hipMemcpyHostToDevice, c->stream));
+    PCP_CHECK(hipMemcpyAsync(c->a, a_xyzw, (size_t)n_a * sizeof(float4), kind, c->stream));
     PCP_CHECK(hipMemcpyAsync(c->scan, lines.data(), lines.size() * sizeof(int2), hipMemcpyHostToDevice, c->stream));
     PCP_CHECK(hipStreamSynchronize(c->stream));   // `lines` dies with this frame
     c->origin = make_float4(origin4[0], origin4[1], origin4[2], origin4[3]);

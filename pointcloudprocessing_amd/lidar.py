@@ -105,3 +105,61 @@ def synthetic_pair(seed=0, yaw=0.012, forward=0.85):
     R = rotation_xyz(0.0, yaw, 0.0)
     b = synthetic_scan(seed + 1, pose_R=R, pose_t=np.array([forward, 0.0, 0.03]))
     return a, b
+
+
+class LidarDataReader:
+    """The velodyne half of the reference's reader (LidarDataReader.py:9-260): frames keyed by file
+    stem, decoded, ego-filtered and rotated.  Camera colouring is not reproduced: colours are the
+    intensities, which is what createColors (:96-101) starts from.  Files are read in sorted order."""
+
+    VELODYNE_DATA = "velodyne_points/data"
+    DEFAULT_COLOR = np.array([255, 178, 102])
+
+    def __init__(self):
+        self.datamap = {}
+        self.root = None
+        self.count = 0
+        self.inited = False
+
+    def init(self, path, calibration=None, targetCamera="02", max_read=10, ui=None):
+        import os
+        self.root = path
+        folder = os.path.join(path, self.VELODYNE_DATA)
+        for name in sorted(n for n in os.listdir(folder) if n.endswith(".bin")):
+            raw = np.fromfile(os.path.join(folder, name), dtype=np.float32).reshape(-1, 4)
+            self.add_frame(name[:-4], raw)
+            if self.count >= max_read:
+                break
+        self.inited = True
+
+    def add_frame(self, key, raw_xyzi):
+        raw = np.asarray(raw_xyzi, dtype=np.float32)
+        keep = np.linalg.norm(raw[:, :3], axis=1) > 2.5
+        points = (aligning_rotation() @ raw[keep, :3].T).T
+        int_cls = np.tile(raw[keep, 3].T.reshape(-1, 1), 3)
+        self.datamap[key] = (points, int_cls.copy(), int_cls)
+        self.count += 1
+
+    def cleanup(self):
+        self.inited = False
+        self.datamap.clear()
+        self.count = 0
+
+    def getPoints(self, filename):
+        d = self.datamap[filename]
+        return np.ascontiguousarray(d[0]), np.ascontiguousarray(d[1])
+
+    def getPointsWithIntensities(self, filename):
+        d = self.datamap[filename]
+        return np.ascontiguousarray(d[0]), np.ascontiguousarray(d[1]), d[2]
+
+    def getfilenames(self):
+        return list(self.datamap.keys())
+
+    @staticmethod
+    def aligningRotation():
+        return aligning_rotation()
+
+    @staticmethod
+    def rotation(x, y, z):
+        return rotation_xyz(x, y, z)
