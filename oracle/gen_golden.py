@@ -8,6 +8,7 @@ Needs /root/reference (read-only).  Three kinds of vectors:
                    (PointcloudIcpContainer, PointcloudAlignment), the known
                    answers that pin the restatement in oracle/np_oracle.py
   ref_voxel.npz    the reference's own Voxelizer (CPU path) on the two KITTI frames
+  ref_arena.npz    the reference's point arena (GpuMemoryManager) through a scripted alloc/free sequence
   ref_imu.npz      the reference's odometry driver in IMU-only mode over the sample OXTS records
   ref_kd.npz       the reference's legacy KD-tree ICP (icp_step_KD, align_KD) on the pair
   oracle_kitti.npz outputs of oracle/np_oracle.py on the KITTI pair (full-size
@@ -218,6 +219,33 @@ def ref_imu():
     np.savez_compressed(os.path.join(OUT, "ref_imu.npz"), **out)
 
 
+def ref_arena():
+    """The reference's point arena (GpuMemoryManager.py) driven through a scripted sequence of
+    allocations and frees: the bookkeeping after every step and the arena contents at the end."""
+    sys.path.insert(0, REF)
+    from GpuMemoryManager import GpuMemoryManager
+    rng = np.random.default_rng(21)
+    m = GpuMemoryManager(maxNumberOfPoints=64)
+    clouds = [rng.uniform(-1, 1, (n, 6)) for n in (5, 9, 1, 12, 7, 20, 3)]
+    script = [("add", 0), ("add", 1), ("add", 2), ("free", 1), ("add", 3), ("free", 0), ("mark", 0), ("add", 4),
+              ("add", 5), ("free", 3), ("add", 6), ("free", 2), ("free", 6)]
+    handles, states = {}, []
+    for op, k in script:
+        moved = -1
+        if op == "add":
+            handles[k] = m.addPoints(clouds[k])
+        elif op == "free":
+            moved = int(m.freeSpace(handles[k]))
+        else:
+            m.markLastBufferPoint()
+        states.append([moved, m.getMaxPointIndex(), m.last_buffered_point, len(m.pointers)] +
+                      [v for a in m.allocationIndexes for v in a] + [-1] * (3 * 8 - 3 * len(m.allocationIndexes)))
+    out = {f"cloud{i}": c for i, c in enumerate(clouds)}
+    out.update(script_ops=np.array([o for o, _ in script]), script_args=np.array([k for _, k in script]),
+               states=np.array(states, dtype=np.int64), points=m.points.copy())
+    np.savez_compressed(os.path.join(OUT, "ref_arena.npz"), **out)
+
+
 def oracle_kitti(frames):
     from oracle import np_oracle as O
     A, B = frames
@@ -254,6 +282,8 @@ if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     raw = kitti_pair()
     frames = ref_kat(raw)
+    if "--no-arena" not in sys.argv:
+        ref_arena()
     if "--no-imu" not in sys.argv:
         ref_imu()
     if "--no-kd" not in sys.argv:
