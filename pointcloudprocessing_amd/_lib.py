@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpcp.so")
+LIB_PATH = os.environ.get("PCP_LIB_PATH") or os.path.join(_HERE, "libpcp.so")
 
 _lib = None
 

@@ -31,6 +31,7 @@ struct pcp_ctx {
     uint32_t* nn_idx = nullptr;
     int2* scan = nullptr;
     float4* ring_stat = nullptr;   // per ring: (sin, cos) of lowest and highest elevation
+    float4* ring_bins = nullptr;   // the same per ring and azimuth bin (PCP_AZ_BINS per ring)
     float *partials = nullptr, *lvl0 = nullptr, *lvl1 = nullptr;
     float *hb_trace = nullptr, *dx_trace = nullptr;   // max_iter_cap x 64 / x 6
     IcpState* state = nullptr;

@@ -58,19 +58,35 @@ __device__ __forceinline__ void load_rings(char* smem, const int2* __restrict__ 
     s_stat = st;
 }
 
+// Order-preserving map between floats and ints, for integer atomicMin / atomicMax on LDS.
+__device__ __forceinline__ int float_key(const float f) {
+    const int i = __float_as_int(f);
+    return i ^ ((i >> 31) & 0x7fffffff);
+}
+__device__ __forceinline__ float key_float(const int k) { return __int_as_float(k ^ ((k >> 31) & 0x7fffffff)); }
+
 // Elevation band of every ring: (sin, cos) of the lowest and of the highest
-// unit-vector elevation among its points.  One wave per ring.
+// unit-vector elevation among its points, for the whole ring (stat[r]) and, per
+// azimuth bin b, for the points in bins b-1, b, b+1 (bins[b][r]; cos < 0 = none).
+// One wave per ring.
 __device__ __forceinline__ void ring_stats_body(const float4* __restrict__ ua, const int2* __restrict__ scan,
-                                                int Z, float4* __restrict__ stat, const int r) {
+                                                int Z, float4* __restrict__ stat, float4* __restrict__ bins,
+                                                const int r) {
+    __shared__ int blo[PCP_AZ_BINS], bhi[PCP_AZ_BINS];
     if (r >= Z) return;
     const int2 se = scan[r];
+    for (int b = threadIdx.x; b < PCP_AZ_BINS; b += 64) { blo[b] = float_key(2.0f); bhi[b] = float_key(-2.0f); }
+    __syncthreads();
     float lo = 2.0f, hi = -2.0f;
     bool bad = false;
     for (int p = se.x + (int)threadIdx.x; p <= se.y; p += 64) {
-        const float y = ua[p].y;
-        if (y != y) bad = true;
-        lo = fminf(lo, y);
-        hi = fmaxf(hi, y);
+        const float4 u = ua[p];
+        if (u.y != u.y || u.x != u.x || u.z != u.z) { bad = true; continue; }
+        lo = fminf(lo, u.y);
+        hi = fmaxf(hi, u.y);
+        const int b = az_bin(u.x, u.z);
+        atomicMin(&blo[b], float_key(u.y));
+        atomicMax(&bhi[b], float_key(u.y));
     }
 #pragma unroll
     for (int s = 32; s > 0; s >>= 1) {
@@ -78,23 +94,34 @@ __device__ __forceinline__ void ring_stats_body(const float4* __restrict__ ua, c
         hi = fmaxf(hi, __shfl_xor(hi, s, 64));
     }
     bad = __any(bad);
-    if (threadIdx.x == 0) {
-        const float clo = (float)sqrt(fmax(0.0, 1.0 - (double)lo * (double)lo));
-        const float chi = (float)sqrt(fmax(0.0, 1.0 - (double)hi * (double)hi));
-        const float nan = __int_as_float(0x7fc00000);
-        if (bad || !(clo > 0.05f) || !(chi > 0.05f) || lo > hi) stat[r] = make_float4(nan, nan, nan, nan);
-        else stat[r] = make_float4(lo, clo, hi, chi);
+    __syncthreads();
+    const float nan = __int_as_float(0x7fc00000);
+    const float clo = (float)sqrt(fmax(0.0, 1.0 - (double)lo * (double)lo));
+    const float chi = (float)sqrt(fmax(0.0, 1.0 - (double)hi * (double)hi));
+    const bool unusable = bad || !(clo > 0.05f) || !(chi > 0.05f) || lo > hi;
+    if (threadIdx.x == 0) stat[r] = unusable ? make_float4(nan, nan, nan, nan) : make_float4(lo, clo, hi, chi);
+    for (int b = threadIdx.x; b < PCP_AZ_BINS; b += 64) {
+        const int l = (b + PCP_AZ_BINS - 1) % PCP_AZ_BINS, h = (b + 1) % PCP_AZ_BINS;
+        const float mlo = key_float(min(blo[b], min(blo[l], blo[h])));
+        const float mhi = key_float(max(bhi[b], max(bhi[l], bhi[h])));
+        float4 out;
+        if (unusable) out = make_float4(nan, nan, nan, nan);
+        else if (mlo > mhi) out = make_float4(0.0f, -1.0f, 0.0f, -1.0f);          // no point in the three bins
+        else out = make_float4(mlo, (float)sqrt(fmax(0.0, 1.0 - (double)mlo * (double)mlo)),
+                               mhi, (float)sqrt(fmax(0.0, 1.0 - (double)mhi * (double)mhi)));
+        bins[(size_t)b * Z + r] = out;
     }
 }
 
 __global__ void __launch_bounds__(64)
-k_ring_stats(const float4* __restrict__ ua, const int2* __restrict__ scan, int Z, float4* __restrict__ stat) {
-    ring_stats_body(ua, scan, Z, stat, blockIdx.x);
+k_ring_stats(const float4* __restrict__ ua, const int2* __restrict__ scan, int Z, float4* __restrict__ stat,
+             float4* __restrict__ bins) {
+    ring_stats_body(ua, scan, Z, stat, bins, blockIdx.x);
 }
 
 // Prepare-phase kernels for a batch: blockIdx.y / blockIdx.z selects the pair.
 struct PrepArgs {
-    const float4* a; float4* ua; float4* normals; const int2* scan; float4* stat; float* hint;
+    const float4* a; float4* ua; float4* normals; const int2* scan; float4* stat; float4* bins; float* hint;
     int n_a, Z, max_points; float4 o;
 };
 
@@ -107,21 +134,22 @@ __global__ void k_unit_batch(const PrepArgs* __restrict__ all) {
 
 __global__ void __launch_bounds__(64) k_ring_stats_batch(const PrepArgs* __restrict__ all) {
     const PrepArgs P = all[blockIdx.y];
-    ring_stats_body(P.ua, P.scan, P.Z, P.stat, blockIdx.x);
+    ring_stats_body(P.ua, P.scan, P.Z, P.stat, P.bins, blockIdx.x);
 }
 
 // NearestNeighbourScan.glsl:1-35.  One wave per block = one shader workgroup.
 __global__ void __launch_bounds__(PCP_BLOCK)
 k_nn(const float4* __restrict__ a, const float4* __restrict__ ua, const int2* __restrict__ scan,
-     const float4* __restrict__ stat, int n_a, int Z, float4 o, const float4* __restrict__ b, int n_b,
-     float* __restrict__ hint, uint32_t* __restrict__ idx, float* __restrict__ dist) {
+     const float4* __restrict__ stat, const float4* __restrict__ bins, int n_a, int Z, float4 o,
+     const float4* __restrict__ b, int n_b, float* __restrict__ hint, uint32_t* __restrict__ idx,
+     float* __restrict__ dist) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int2* s_scan;
     const float4* s_stat;
     load_rings(smem, scan, stat, Z, s_scan, s_stat);
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const bool in = i < n_b;
-    const Target T{a, ua, s_scan, s_stat, n_a, Z, o};
+    const Target T{a, ua, s_scan, s_stat, bins, n_a, Z, o};
     const float4 q = in ? b[i] : make_float4(0.f, 0.f, 0.f, 0.f);
     float h = in ? hint[i] : -1.0f;
     if (!in) return;
@@ -150,7 +178,7 @@ __device__ __forceinline__ void normals_body(const float4* __restrict__ a, const
     load_rings(smem, scan, stat, Z, s_scan, s_stat);
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_a) return;
-    const Target T{a, ua, s_scan, s_stat, n_a, Z, o};
+    const Target T{a, ua, s_scan, s_stat, nullptr, n_a, Z, o};
     // getScanLineOfPoint, NormalShader.glsl:1-10: first ring that contains the point
     int ring = -1;
     for (int r = 0; r < Z; ++r) {
@@ -211,7 +239,7 @@ __global__ void __launch_bounds__(PCP_BLOCK) k_normals_batch(const PrepArgs* __r
 //           left pending by the previous iteration is applied first
 //           (apply_iteration_of_ls, PointcloudIcpContainer.py:172-174).
 struct LsArgs {
-    const float4* a; const float4* ua; const int2* scan; const float4* stat;
+    const float4* a; const float4* ua; const int2* scan; const float4* stat; const float4* bins;
     int n_a, Z; float4 o;
     const float4* normals; const float4* b32; const double* b_in; double* b64; IcpState* st;
     int n_b, debug;
@@ -260,7 +288,7 @@ __device__ __forceinline__ void ls_body(const LsArgs& A, char* smem) {
             q = A.b32[i];
         }
     }
-    const Target T{a, A.ua, s_scan, s_stat, A.n_a, A.Z, A.o};
+    const Target T{a, A.ua, s_scan, s_stat, A.bins, A.n_a, A.Z, A.o};
     int nn = in ? i : 0;      // debug_info.x >= 1: identity correspondences, LeastSquaresPoint.glsl:78-81
     float d = 0.0f;
     if (!debug) {
@@ -430,7 +458,7 @@ int upload_b32(pcp_ctx* c, const float* b_xyzw, int n_b) {
 LsArgs ls_args(const pcp_ctx* c, int debug, float* tiles) {
     LsArgs A;
     memset(&A, 0, sizeof(A));          // padding bytes too: descriptors are compared with memcmp
-    A.a = c->a; A.ua = c->ua; A.scan = c->scan; A.stat = c->ring_stat;
+    A.a = c->a; A.ua = c->ua; A.scan = c->scan; A.stat = c->ring_stat; A.bins = c->ring_bins;
     A.n_a = c->n_a; A.Z = c->n_scans; A.o = c->origin;
     A.normals = c->normals; A.b32 = c->b32; A.b_in = c->b_in; A.b64 = c->b64; A.st = c->state;
     A.n_b = c->n_b; A.debug = debug;
@@ -540,6 +568,7 @@ int pcp_create(int device, int max_points, int max_scans, pcp_ctx** out) {
     A((void**)&c->nn_idx, n * sizeof(uint32_t));
     A((void**)&c->scan, (size_t)max_scans * sizeof(int2));
     A((void**)&c->ring_stat, (size_t)max_scans * sizeof(float4));
+    A((void**)&c->ring_bins, (size_t)max_scans * PCP_AZ_BINS * sizeof(float4));
     A((void**)&c->partials, (size_t)n1 * PCP_PSTRIDE * sizeof(float));
     A((void**)&c->lvl0, (size_t)n2 * PCP_PSTRIDE * sizeof(float));
     A((void**)&c->lvl1, (size_t)n2 * PCP_PSTRIDE * sizeof(float));
@@ -563,7 +592,7 @@ int pcp_destroy(pcp_ctx* c) {
     if (!c) return 0;
     (void)hipSetDevice(c->device);
     if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
-    void* bufs[] = {c->a, c->ua, c->normals, c->b32, c->b_in, c->b64, c->hint, c->nn_dist, c->nn_idx, c->scan, c->ring_stat,
+    void* bufs[] = {c->a, c->ua, c->normals, c->b32, c->b_in, c->b64, c->hint, c->nn_dist, c->nn_idx, c->scan, c->ring_stat, c->ring_bins,
                     c->partials, c->lvl0, c->lvl1, c->hb_trace, c->dx_trace, c->state, c->tiles, c->tiles2};
     for (void* p : bufs)
         if (p) (void)hipFree(p);
@@ -600,7 +629,7 @@ int pcp_prepare_resident(pcp_ctx* c, int with_normals) {
     if (!c->have_target) return pcp_fail("no target: call pcp_set_target first");
     hipLaunchKernelGGL(k_unit, dim3(cdiv(c->n_a, 256)), dim3(256), 0, c->stream, c->a, c->ua, c->n_a, c->origin);
     PCP_CHECK(hipGetLastError());
-    hipLaunchKernelGGL(k_ring_stats, dim3(c->n_scans), dim3(64), 0, c->stream, c->ua, c->scan, c->n_scans, c->ring_stat);
+    hipLaunchKernelGGL(k_ring_stats, dim3(c->n_scans), dim3(64), 0, c->stream, c->ua, c->scan, c->n_scans, c->ring_stat, c->ring_bins);
     PCP_CHECK(hipGetLastError());
     if (int e = pcp_reset_hints(c)) return e;
     if (with_normals) {
@@ -672,7 +701,7 @@ int pcp_nn(pcp_ctx* c, const float* b_xyzw, int n_b, uint32_t* idx, float* dist2
     if (int e = use(c)) return e;
     if (!idx || !dist2) return pcp_fail("null output");
     if (int e = upload_b32(c, b_xyzw, n_b)) return e;
-    hipLaunchKernelGGL(k_nn, dim3(cdiv(n_b, PCP_BLOCK)), dim3(PCP_BLOCK), scan_smem(c), c->stream, c->a, c->ua, c->scan, c->ring_stat,
+    hipLaunchKernelGGL(k_nn, dim3(cdiv(n_b, PCP_BLOCK)), dim3(PCP_BLOCK), scan_smem(c), c->stream, c->a, c->ua, c->scan, c->ring_stat, c->ring_bins,
                        c->n_a, c->n_scans, c->origin, c->b32, n_b, c->hint, c->nn_idx, c->nn_dist);
     PCP_CHECK(hipGetLastError());
     PCP_CHECK(hipMemcpyAsync(idx, c->nn_idx, (size_t)n_b * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
@@ -929,7 +958,7 @@ int pcp_batch_prepare(pcp_batch* b, int with_normals) {
         if (with_normals && c->n_scans < 2) return pcp_fail("pair %d: normals need at least 2 scan lines", i);
         PrepArgs P;
         memset(&P, 0, sizeof(P));
-        P.a = c->a; P.ua = c->ua; P.normals = c->normals; P.scan = c->scan; P.stat = c->ring_stat; P.hint = c->hint;
+        P.a = c->a; P.ua = c->ua; P.normals = c->normals; P.scan = c->scan; P.stat = c->ring_stat; P.bins = c->ring_bins; P.hint = c->hint;
         P.n_a = c->n_a; P.Z = c->n_scans; P.max_points = c->max_points; P.o = c->origin;
         want[i] = P;
         max_na = c->n_a > max_na ? c->n_a : max_na;
@@ -1063,6 +1092,18 @@ int pcp_batch_profile_read(pcp_batch* b, float* ls_ms, int* launches, long long*
     *points = pts;
     return 0;
 }
+
+#ifdef PCP_STATS
+int pcp_stats_read(unsigned long long* out8, int reset) {
+    PCP_CHECK(hipDeviceSynchronize());
+    PCP_CHECK(hipMemcpyFromSymbol(out8, HIP_SYMBOL(pcp_stats), 64));
+    if (reset) {
+        unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        PCP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(pcp_stats), z, 64));
+    }
+    return 0;
+}
+#endif
 
 int pcp_timer_start(pcp_ctx* c) {
     if (int e = use(c)) return e;
