@@ -225,7 +225,7 @@ k_normals(const float4* __restrict__ a, const float4* __restrict__ ua, const int
     normals_body(a, ua, scan, stat, n_a, Z, o, normals, smem);
 }
 
-__global__ void __launch_bounds__(PCP_BLOCK) k_normals_batch(const PrepArgs* __restrict__ all) {
+__global__ void __launch_bounds__(PCP_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) k_normals_batch(const PrepArgs* __restrict__ all) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const PrepArgs P = all[blockIdx.y];
     if ((int)(blockIdx.x * PCP_BLOCK) >= P.n_a) return;
@@ -339,7 +339,7 @@ __global__ void __launch_bounds__(PCP_BLOCK) k_ls(const LsArgs A) {
 
 // The same for a batch of independent pairs: blockIdx.y selects the pair.
 template <int MODE>
-__global__ void __launch_bounds__(PCP_BLOCK) k_ls_batch(const LsArgs* __restrict__ all) {
+__global__ void __launch_bounds__(PCP_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) k_ls_batch(const LsArgs* __restrict__ all) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const LsArgs A = all[blockIdx.y];
     if ((int)(blockIdx.x * PCP_BLOCK) >= A.n_b) return;
