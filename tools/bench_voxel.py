@@ -1,0 +1,25 @@
+"""Voxel map leg: Voxelizer.addPoints on the two KITTI frames (0.5 m), staging, and the split of the time."""
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from pointcloudprocessing_amd import ComputeShader, Voxelizer, lidar  # noqa: E402
+
+g = np.load(os.path.join(os.path.dirname(__file__), "..", "tests", "golden", "kitti_pair.npz"))
+frames = [lidar.frame_from_raw(g["raw0"]), lidar.frame_from_raw(g["raw1"])]
+cs = ComputeShader(maxPointsPerCloud=200000)
+for rep in range(2):
+    v = Voxelizer(cs, None)
+    v.init(0.5)
+    for k, f in enumerate(frames * 2):
+        t0 = time.perf_counter()
+        v.addPoints(f, None)
+        dt = time.perf_counter() - t0
+        print(f"rep {rep} frame {k}: addPoints {dt * 1e3:7.2f} ms, {v.stored_voxels} voxels, {v.last_added_point} points")
+    t0 = time.perf_counter()
+    v.stageAllRemaningVoxels() if hasattr(v, "stageAllRemaningVoxels") else None
+    print(f"rep {rep}: stageAllRemaningVoxels {(time.perf_counter() - t0) * 1e3:7.2f} ms")
+cs.cleanup()
