@@ -1,8 +1,9 @@
-"""Input clouds for tests and benchmarks.
+"""Input clouds.
 
-* The three numeric steps of the reference's KITTI reader that shape a frame
-  before registration (LidarDataReader.py:144-150 decode, :59-61 ego filter,
-  :66-67 + :139-142 axis-aligning rotation).
+* frame_from_raw / load_velodyne_bin: the three numeric steps of the reference's KITTI reader that
+  shape a frame before registration (LidarDataReader.py:144-150 decode, :59-61 ego filter,
+  :66-67 + :139-142 axis-aligning rotation) in NumPy, for test and benchmark inputs; the product's
+  reader (class LidarDataReader below) runs them on the device.
 * A deterministic synthetic 64-ring spinning-LiDAR scan of a box scene with the
   size and ring structure of a KITTI sweep (about 120k points), for machines
   that hold no KITTI data.
@@ -109,17 +110,20 @@ def synthetic_pair(seed=0, yaw=0.012, forward=0.85):
 
 class LidarDataReader:
     """The velodyne half of the reference's reader (LidarDataReader.py:9-260): frames keyed by file
-    stem, decoded, ego-filtered and rotated.  Camera colouring is not reproduced: colours are the
+    stem, decoded, ego-filtered and rotated -- on the device (frame.DeviceFrame), read back once because
+    the reader's interface hands out host arrays.  Camera colouring is not reproduced: colours are the
     intensities, which is what createColors (:96-101) starts from.  Files are read in sorted order."""
 
     VELODYNE_DATA = "velodyne_points/data"
     DEFAULT_COLOR = np.array([255, 178, 102])
 
-    def __init__(self):
+    def __init__(self, device=0):
         self.datamap = {}
         self.root = None
         self.count = 0
         self.inited = False
+        self.device = device
+        self._frame = None
 
     def init(self, path, calibration=None, targetCamera="02", max_read=10, ui=None):
         import os
@@ -128,15 +132,22 @@ class LidarDataReader:
         for name in sorted(n for n in os.listdir(folder) if n.endswith(".bin")):
             raw = np.fromfile(os.path.join(folder, name), dtype=np.float32).reshape(-1, 4)
             self.add_frame(name[:-4], raw)
+            if ui is not None:
+                ui.setFrameCounter(self.count, max_read)
             if self.count >= max_read:
                 break
         self.inited = True
 
     def add_frame(self, key, raw_xyzi):
-        raw = np.asarray(raw_xyzi, dtype=np.float32)
-        keep = np.linalg.norm(raw[:, :3], axis=1) > 2.5
-        points = (aligning_rotation() @ raw[keep, :3].T).T
-        int_cls = np.tile(raw[keep, 3].T.reshape(-1, 1), 3)
+        from .frame import DeviceFrame
+        raw = np.ascontiguousarray(raw_xyzi, dtype=np.float32)
+        if self._frame is None or self._frame.max_points < len(raw):
+            if self._frame is not None:
+                self._frame.cleanup()
+            self._frame = DeviceFrame(max_points=max(len(raw), 200000), device=self.device)
+        self._frame.decode(raw, min_range=2.5, rotation=aligning_rotation())
+        points, intensities = self._frame.read(intensities=True)
+        int_cls = np.tile(intensities.T.reshape(-1, 1), 3)
         self.datamap[key] = (points, int_cls.copy(), int_cls)
         self.count += 1
 
@@ -144,6 +155,9 @@ class LidarDataReader:
         self.inited = False
         self.datamap.clear()
         self.count = 0
+        if self._frame is not None:
+            self._frame.cleanup()
+            self._frame = None
 
     def getPoints(self, filename):
         d = self.datamap[filename]

@@ -59,6 +59,25 @@ def test_decode_edge_cases(frame):
         frame.decode(np.zeros((200001, 4), np.float32))
 
 
+def test_lidar_reader_decodes_on_the_device_and_keeps_the_reference_interface(tmp_path):
+    pair, k = golden("kitti_pair.npz"), golden("ref_kat.npz")
+    folder = tmp_path / "velodyne_points" / "data"
+    folder.mkdir(parents=True)
+    for i in (1, 0):                                                  # written out of order, read sorted
+        raw4(pair[f"raw{i}"], i).tofile(folder / f"{i:010d}.bin")
+    rd = lidar.LidarDataReader()
+    rd.init(str(tmp_path), max_read=10)
+    try:
+        assert rd.getfilenames() == ["0000000000", "0000000001"] and rd.count == 2
+        for i, key in enumerate(rd.getfilenames()):
+            pts, colors, inten = rd.getPointsWithIntensities(key)
+            assert sha(pts) == str(k[f"frame{i}_sha"]) and pts.flags["C_CONTIGUOUS"]
+            assert inten.shape == (len(pts), 3) and np.array_equal(inten[:, 0], inten[:, 2])
+            assert np.array_equal(colors, inten) and np.array_equal(rd.getPoints(key)[0], pts)
+    finally:
+        rd.cleanup()
+
+
 def test_move_and_scan_lines_of_an_uploaded_cloud(frame):
     a, _ = kitti_pair()
     R = lidar.rotation_xyz(0.01, 0.3, -0.02)

@@ -280,3 +280,28 @@ def test_sequence_odometry_recovers_a_synthetic_trajectory():
     assert np.abs(R_opt - R_rel).max() < 5e-3 and np.abs(-t_opt - t_rel).max() < 5e-2
     t_pp, R_pp = register_pairs([frames[0]], [frames[1]], point_to_plane=False, iterations=3, guesses=[guess])[0]
     assert np.isfinite(t_pp).all() and np.abs(R_pp @ R_pp.T - np.eye(3)).max() < 1e-9
+
+
+@pytest.mark.parametrize("plane", [False, True])
+def test_perturbed_kitti_frame_converges_like_the_reference_scenario(compute, plane):
+    """tests/FunctionalTesting.py:348-365 / :456-475: a frame against a copy of itself moved by
+    randomRotation(0.01), randomTranslation1() * 0.01 (random.seed(0)); the reference only displays the
+    result, here the recovered pose must undo the perturbation."""
+    import random
+    from pointcloudprocessing_amd import PointcloudAlignment
+    a, _ = kitti_pair()
+    random.seed(0)
+    randrot = PointcloudAlignment.randomRotation(0.01)
+    randtrans = PointcloudAlignment.randomTranslation1() * 0.01
+    moved = (randrot @ a.T).T + randtrans
+    icp = PointcloudIcpContainer(compute)
+    if plane:
+        t_opt, R_opt = icp.full_pt2pl(a, moved, np.zeros(3), iterations=20)
+    else:
+        t_opt, R_opt = icp.full_pt2pt(a, moved, np.zeros(3), iterations=40)
+    back = (R_opt @ moved.T).T - t_opt
+    err = np.linalg.norm(back - a, axis=1)
+    tol_R, tol_t, tol_p = (2e-4, 2e-3, 5e-3) if plane else (3e-3, 3e-2, 0.15)    # point-to-point creeps
+    assert np.abs(R_opt @ randrot - np.eye(3)).max() < tol_R
+    assert np.abs(R_opt @ randtrans - t_opt).max() < tol_t
+    assert np.median(err) < tol_p
