@@ -149,6 +149,21 @@ int pcp_voxel_data_read(pcp_ctx* ctx, int rows, int max_points, int32_t* out);
 int pcp_voxelize(pcp_ctx* ctx, const float* pts_xyzw, int n, float voxel_size, int stored,
                  int begin_index, int max_points, int32_t* unknown, int unknown_len,
                  float* debug);
+/* The host half of Voxelizer.storeUnknownPoints (Voxelizer.py:170-306) on the device, for the
+ * unknown points of the LAST pcp_voxelize call (its points and unknown list are still resident):
+ * one new voxel per distinct coordinate, in lexicographic order; data row stored + rank holds the
+ * count of all its points and the first max_points - 1 ids (ascending); the entries are merged
+ * into the sorted table.  Table and data grow on the device by the reference's rule (rows double
+ * while new_stored >= rows, :238-252).  new_stored = voxels now in the table, rows_capacity = rows
+ * the device data now has.  Fails if a voxel of an unknown point already exists (:228-229). */
+int pcp_voxel_insert_unknown(pcp_ctx* ctx, int max_points, int* new_stored, int* rows_capacity);
+/* Forget the resident voxel map (table and data are freed). */
+int pcp_voxel_reset(pcp_ctx* ctx);
+/* Device table / data of at least `rows` rows (contents kept, new data rows zero). */
+int pcp_voxel_reserve(pcp_ctx* ctx, int rows, int max_points);
+/* The first `rows` table entries (vx, vy, vz, data row) / the counts of n_rows data rows. */
+int pcp_voxel_index_read(pcp_ctx* ctx, int rows, int32_t* voxel_index);
+int pcp_voxel_counts_read(pcp_ctx* ctx, int first_row, int n_rows, int32_t* counts);
 /* prepareDispatchVoxelStager (:761-835), kernel VoxelStage.glsl, on the table
  * and voxel data already resident.  voxel_stat (stat_rows x 4) is uploaded,
  * updated and read back in place; counter16 receives the counter buffer

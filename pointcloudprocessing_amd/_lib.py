@@ -90,6 +90,11 @@ SIGNATURES = {
     "pcp_frame_read": (C.c_int, [C.c_void_p, _f64p, _f32p]),
     "pcp_frame_points_dev": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
     "pcp_frame_padded_dev": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
+    "pcp_voxel_insert_unknown": (C.c_int, [_ctx, C.c_int, _i32p, _i32p]),
+    "pcp_voxel_reset": (C.c_int, [_ctx]),
+    "pcp_voxel_reserve": (C.c_int, [_ctx, C.c_int, C.c_int]),
+    "pcp_voxel_index_read": (C.c_int, [_ctx, C.c_int, _i32p]),
+    "pcp_voxel_counts_read": (C.c_int, [_ctx, C.c_int, C.c_int, _i32p]),
     "pcp_batch_create": (C.c_int, [C.POINTER(_ctx), C.c_int, C.POINTER(C.c_void_p)]),
     "pcp_batch_destroy": (C.c_int, [C.c_void_p]),
     "pcp_batch_prepare": (C.c_int, [C.c_void_p, C.c_int]),

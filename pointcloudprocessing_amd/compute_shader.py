@@ -43,6 +43,7 @@ class ComputeShader:
         self._ctx = C.c_void_p()
         check(self._lib.pcp_create(int(device), int(maxPointsPerCloud), int(maxScans), C.byref(self._ctx)))
         self._active = None          # which prepare* ran last
+        self._voxel_resident = None  # voxel count of a map whose device copy is the authority, else None
         self.reallocate_out(np.array([maxPointsPerCloud, maxPointsPerCloud, 0, 0]))
 
     # ------------------------------------------------------------------ helpers
@@ -198,11 +199,40 @@ class ComputeShader:
         """:837-840"""
         vi = np.ascontiguousarray(voxel_index, dtype=np.int32)
         check(self._lib.pcp_voxel_index_upload(self._ctx, i32p(vi), len(vi)))
+        self._voxel_resident = None           # the host copy is the authority again
 
     def fullBufferVoxelData(self, voxel_data):
         """:842-845"""
         vd = np.ascontiguousarray(voxel_data, dtype=np.int32)
         check(self._lib.pcp_voxel_data_upload(self._ctx, i32p(vd), vd.shape[0], vd.shape[1]))
+        self._voxel_resident = None
+
+    # -- voxel map kept on the device (no counterpart in the reference, whose host recreates and
+    #    re-uploads table and rows every frame)
+    def voxelReserve(self, rows, max_points):
+        """Fresh, empty device table / data of `rows` rows; the device copy becomes the authority."""
+        check(self._lib.pcp_voxel_reset(self._ctx))
+        check(self._lib.pcp_voxel_reserve(self._ctx, int(rows), int(max_points)))
+        self._voxel_resident = 0
+
+    def insertUnknownVoxels(self, max_points):
+        """Voxelizer.storeUnknownPoints (Voxelizer.py:170-306) on the device for the unknown points of the
+        last prepareDispatchVoxelizer call -> (stored voxels now, data rows the device has)."""
+        stored, cap = C.c_int(0), C.c_int(0)
+        check(self._lib.pcp_voxel_insert_unknown(self._ctx, int(max_points), C.byref(stored), C.byref(cap)))
+        self._voxel_resident = stored.value
+        return stored.value, cap.value
+
+    def readVoxelIndex(self, rows, voxel_index):
+        """Fills voxel_index[:rows] (int32, C-contiguous) from the device table."""
+        if voxel_index.dtype != np.int32 or not voxel_index.flags.c_contiguous:
+            raise PcpError("voxel_index must be a C-contiguous int32 array")
+        check(self._lib.pcp_voxel_index_read(self._ctx, int(rows), i32p(voxel_index)))
+
+    def readVoxelCounts(self, first_row, n_rows):
+        out = np.zeros(int(n_rows), dtype=np.int32)
+        check(self._lib.pcp_voxel_counts_read(self._ctx, int(first_row), int(n_rows), i32p(out)))
+        return out
 
     def prepareDispatchVoxelizer(self, np_points, voxel_index, voxel_data, voxel_size, stored_voxel_num,
                                  begin_index, max_points_to_store, realloc_needed, prev_stored_voxels,
@@ -214,13 +244,16 @@ class ComputeShader:
         unknown_len = 1 + n
         unknown_len += 16 - unknown_len % 16
         unknown_points = np.zeros(unknown_len, dtype=np.int32)
-        self.bufferVoxelIndex(voxel_index)
-        if realloc_needed:
-            self.fullBufferVoxelData(voxel_data)
+        if self._voxel_resident is not None and self._voxel_resident == int(stored_voxel_num):
+            pass        # table and rows were created on the device (insertUnknownVoxels): nothing to upload
         else:
-            new_rows = np.ascontiguousarray(voxel_data[prev_stored_voxels:stored_voxel_num], dtype=np.int32)
-            check(self._lib.pcp_voxel_data_upload_rows(self._ctx, i32p(new_rows), int(prev_stored_voxels),
-                                                       len(new_rows), int(max_points_to_store)))
+            self.bufferVoxelIndex(voxel_index)
+            if realloc_needed:
+                self.fullBufferVoxelData(voxel_data)
+            else:
+                new_rows = np.ascontiguousarray(voxel_data[prev_stored_voxels:stored_voxel_num], dtype=np.int32)
+                check(self._lib.pcp_voxel_data_upload_rows(self._ctx, i32p(new_rows), int(prev_stored_voxels),
+                                                           len(new_rows), int(max_points_to_store)))
         pts = self.pad_points(np_points)
         debug_data = np.zeros((n, 4), dtype=np.float32) if debug else None
         check(self._lib.pcp_voxelize(self._ctx, f32p(pts), n, float(np.asarray(voxel_size).reshape(-1)[0]),

@@ -19,13 +19,12 @@
 #include <vector>
 
 #include "../../include/pcp.h"
+#include "pcp_compact.h"
 #include "pcp_host.h"
 
-namespace {
+using namespace pcp;
 
-constexpr int FR_THREADS = 256;
-constexpr int FR_ITEMS = 8;
-constexpr int FR_TILE = FR_THREADS * FR_ITEMS;
+namespace {
 
 struct KeepFar {          // ego filter: np.linalg.norm(float32 rows) > min_range
     const float4* raw;
@@ -49,76 +48,6 @@ struct Wrap {             // ring boundary after point i
     }
     __device__ bool operator()(size_t i) const { return fabs(azimuth(i + 1) - azimuth(i)) > 6.0; }
 };
-
-template <class Pred>
-__global__ void __launch_bounds__(FR_THREADS) k_count(const Pred pred, size_t n, unsigned* __restrict__ counts) {
-    __shared__ unsigned total;
-    if (threadIdx.x == 0) total = 0;
-    __syncthreads();
-    const size_t base = (size_t)blockIdx.x * FR_TILE;
-    unsigned mine = 0;
-#pragma unroll
-    for (int k = 0; k < FR_ITEMS; ++k) {
-        const size_t i = base + (size_t)k * FR_THREADS + threadIdx.x;
-        if (i < n && pred(i)) ++mine;
-    }
-#pragma unroll
-    for (int s = 32; s > 0; s >>= 1) mine += __shfl_down(mine, s, 64);
-    if ((threadIdx.x & 63) == 0) atomicAdd(&total, mine);
-    __syncthreads();
-    if (threadIdx.x == 0) counts[blockIdx.x] = total;
-}
-
-// Exclusive prefix of counts[0..nblk) in place; the grand total goes to counts[nblk].
-__global__ void __launch_bounds__(1024) k_scan_counts(unsigned* __restrict__ counts, int nblk) {
-    __shared__ unsigned s[1024];
-    __shared__ unsigned run;
-    if (threadIdx.x == 0) run = 0;
-    __syncthreads();
-    for (int base = 0; base < nblk; base += 1024) {
-        const int i = base + threadIdx.x;
-        const unsigned v = (i < nblk) ? counts[i] : 0u;
-        s[threadIdx.x] = v;
-        __syncthreads();
-        for (int off = 1; off < 1024; off <<= 1) {
-            const unsigned t = (threadIdx.x >= (unsigned)off) ? s[threadIdx.x - off] : 0u;
-            __syncthreads();
-            s[threadIdx.x] += t;
-            __syncthreads();
-        }
-        if (i < nblk) counts[i] = run + s[threadIdx.x] - v;
-        __syncthreads();
-        if (threadIdx.x == 0) run += s[1023];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) counts[nblk] = run;
-}
-
-// Ordered scatter: element i (in index order) with pred(i) goes to slot
-// offsets[block] + its rank inside the block; emit(i, slot) writes it.
-template <class Pred, class Emit>
-__global__ void __launch_bounds__(FR_THREADS)
-k_scatter(const Pred pred, const Emit emit, size_t n, const unsigned* __restrict__ offsets) {
-    __shared__ unsigned wave_total[FR_THREADS / 64];
-    __shared__ unsigned running;
-    if (threadIdx.x == 0) running = offsets[blockIdx.x];
-    __syncthreads();
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const size_t base = (size_t)blockIdx.x * FR_TILE;
-    for (int k = 0; k < FR_ITEMS; ++k) {
-        const size_t i = base + (size_t)k * FR_THREADS + threadIdx.x;
-        const bool keep = i < n && pred(i);
-        const unsigned long long bal = __ballot(keep);
-        if (lane == 0) wave_total[w] = (unsigned)__popcll(bal);
-        __syncthreads();
-        unsigned before = running, all = 0;
-        for (int j = 0; j < FR_THREADS / 64; ++j) { if (j < w) before += wave_total[j]; all += wave_total[j]; }
-        if (keep) emit(i, (size_t)before + (unsigned)__popcll(bal & ((1ull << lane) - 1ull)));
-        __syncthreads();
-        if (threadIdx.x == 0) running += all;
-        __syncthreads();
-    }
-}
 
 struct EmitDecoded {      // rotated float64 point + intensity
     const float4* raw;
@@ -228,9 +157,7 @@ int pcp_frame_decode(pcp_frame* f, const float* raw_xyzi, size_t n, float min_ra
     memcpy(emit.R, R9, sizeof(emit.R));
     emit.xyz = f->xyz;
     emit.intensity = f->intensity;
-    hipLaunchKernelGGL(k_count<KeepFar>, dim3(nblk), dim3(FR_THREADS), 0, f->stream, pred, n, f->counts);
-    hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, f->stream, f->counts, nblk);
-    hipLaunchKernelGGL((k_scatter<KeepFar, EmitDecoded>), dim3(nblk), dim3(FR_THREADS), 0, f->stream, pred, emit, n, f->counts);
+    compact_ordered(f->stream, pred, emit, n, f->counts);
     PCP_CHECK(hipGetLastError());
     unsigned kept = 0;
     PCP_CHECK(hipMemcpyAsync(&kept, f->counts + nblk, 4, hipMemcpyDeviceToHost, f->stream));
@@ -277,9 +204,7 @@ int pcp_frame_scan_lines(pcp_frame* f, const double* origin3, int max_lines, uin
     const int nblk = (int)((m + FR_TILE - 1) / FR_TILE);
     const Wrap pred{f->xyz, origin3[0], origin3[1], origin3[2]};
     const EmitIndex emit{f->ends};
-    hipLaunchKernelGGL(k_count<Wrap>, dim3(nblk), dim3(FR_THREADS), 0, f->stream, pred, m, f->counts);
-    hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, f->stream, f->counts, nblk);
-    hipLaunchKernelGGL((k_scatter<Wrap, EmitIndex>), dim3(nblk), dim3(FR_THREADS), 0, f->stream, pred, emit, m, f->counts);
+    compact_ordered(f->stream, pred, emit, m, f->counts);
     PCP_CHECK(hipGetLastError());
     unsigned found = 0;
     PCP_CHECK(hipMemcpyAsync(&found, f->counts + nblk, 4, hipMemcpyDeviceToHost, f->stream));

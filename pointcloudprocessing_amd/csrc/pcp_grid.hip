@@ -35,6 +35,7 @@
 #include "pcp_device.h"
 #include "pcp_host.h"
 #include "pcp_solve.h"
+#include "pcp_sort.h"
 
 using namespace pcp;
 
@@ -42,7 +43,7 @@ namespace {
 
 struct __align__(32) GridPoint { double x, y, z; long long id; };
 struct __align__(16) Cell { unsigned long long key; unsigned int start, count; };
-constexpr unsigned long long EMPTY_KEY = 0xFFFFFFFFFFFFFFFFull;
+constexpr unsigned long long EMPTY_KEY = RS_EMPTY_KEY;
 constexpr int COORD_BIAS = 1 << 20;          // absolute cell coordinates live in [-2^20, 2^20)
 constexpr int COORD_CLAMP = 1 << 29;
 
@@ -127,123 +128,6 @@ __global__ void k_cell_keys(const double* __restrict__ xyz, size_t n, double cel
     const unsigned z = (unsigned)(cell_of(xyz[3 * i + 2], cell) - cz);
     keys[i] = morton3(x, y, z);
     vals[i] = (unsigned)i;
-}
-
-// LSD radix sort, 8 bits per pass, stable.  A block owns a tile of 2048 keys.
-constexpr int RS_THREADS = 256;
-constexpr int RS_TILE = 2048;
-
-__global__ void __launch_bounds__(RS_THREADS)
-k_rs_hist(const unsigned long long* __restrict__ keys, size_t n, int shift, unsigned* __restrict__ hist, int nblk) {
-    __shared__ unsigned h[256];
-    h[threadIdx.x] = 0;
-    __syncthreads();
-    const size_t base = (size_t)blockIdx.x * RS_TILE;
-#pragma unroll
-    for (int i = 0; i < RS_TILE / RS_THREADS; ++i) {
-        const size_t j = base + (size_t)i * RS_THREADS + threadIdx.x;
-        if (j < n) atomicAdd(&h[(unsigned)(keys[j] >> shift) & 255u], 1u);
-    }
-    __syncthreads();
-    hist[(size_t)threadIdx.x * nblk + blockIdx.x] = h[threadIdx.x];     // digit-major
-}
-
-// Block d: exclusive prefix of hist[d][0..nblk) in place, digit total to totals[d].
-__global__ void __launch_bounds__(256) k_rs_scan(unsigned* __restrict__ hist, int nblk, unsigned* __restrict__ totals) {
-    __shared__ unsigned s[256];
-    unsigned* h = hist + (size_t)blockIdx.x * nblk;
-    unsigned run = 0;
-    for (int base = 0; base < nblk; base += 256) {
-        const int i = base + threadIdx.x;
-        const unsigned v = (i < nblk) ? h[i] : 0u;
-        s[threadIdx.x] = v;
-        __syncthreads();
-        for (int off = 1; off < 256; off <<= 1) {
-            const unsigned t = (threadIdx.x >= (unsigned)off) ? s[threadIdx.x - off] : 0u;
-            __syncthreads();
-            s[threadIdx.x] += t;
-            __syncthreads();
-        }
-        if (i < nblk) h[i] = run + s[threadIdx.x] - v;
-        run += s[255];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) totals[blockIdx.x] = run;
-}
-
-__global__ void __launch_bounds__(256) k_rs_base(const unsigned* __restrict__ totals, unsigned* __restrict__ base) {
-    __shared__ unsigned s[256];
-    const unsigned v = totals[threadIdx.x];
-    s[threadIdx.x] = v;
-    __syncthreads();
-    for (int off = 1; off < 256; off <<= 1) {
-        const unsigned t = (threadIdx.x >= (unsigned)off) ? s[threadIdx.x - off] : 0u;
-        __syncthreads();
-        s[threadIdx.x] += t;
-        __syncthreads();
-    }
-    base[threadIdx.x] = s[threadIdx.x] - v;
-}
-
-// Each wave ranks its own 512 consecutive keys (8 rounds of 64, in order), so
-// the rank of a key among equal digits is: digit base + blocks before + waves
-// before + earlier rounds of this wave + lower lanes of this round.
-__global__ void __launch_bounds__(RS_THREADS)
-k_rs_scatter(const unsigned long long* __restrict__ keys_in, const unsigned* __restrict__ vals_in, size_t n, int shift,
-             const unsigned* __restrict__ hist, const unsigned* __restrict__ base, int nblk,
-             unsigned long long* __restrict__ keys_out, unsigned* __restrict__ vals_out) {
-    __shared__ unsigned cnt[4][256];
-    __shared__ unsigned goff[256];
-    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
-    for (int j = tid; j < 4 * 256; j += RS_THREADS) (&cnt[0][0])[j] = 0;
-    goff[tid] = base[tid] + hist[(size_t)tid * nblk + blockIdx.x];
-    __syncthreads();
-    unsigned long long k[8];
-    unsigned v[8], loc[8];
-    const size_t seg = (size_t)blockIdx.x * RS_TILE + (size_t)w * 512;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const size_t j = seg + (size_t)i * 64 + lane;
-        const bool valid = j < n;
-        k[i] = valid ? keys_in[j] : EMPTY_KEY;
-        v[i] = valid ? vals_in[j] : 0u;
-        const unsigned digit = (unsigned)(k[i] >> shift) & 255u;
-        unsigned long long mask = __ballot(valid);
-#pragma unroll
-        for (int b = 0; b < 8; ++b) {
-            const bool bit = (digit >> b) & 1u;
-            const unsigned long long bm = __ballot(valid && bit);
-            mask &= bit ? bm : ~bm;
-        }
-        int leader = lane;
-        unsigned rank = 0, old = 0;
-        if (valid) {
-            rank = (unsigned)__popcll(mask & ((1ull << lane) - 1ull));
-            leader = __ffsll((long long)mask) - 1;
-            if (lane == leader) old = atomicAdd(&cnt[w][digit], (unsigned)__popcll(mask));
-        }
-        old = __shfl(old, leader, 64);
-        loc[i] = old + rank;
-    }
-    __syncthreads();
-    {
-        const unsigned c0 = cnt[0][tid], c1 = cnt[1][tid], c2 = cnt[2][tid];
-        cnt[0][tid] = 0;
-        cnt[1][tid] = c0;
-        cnt[2][tid] = c0 + c1;
-        cnt[3][tid] = c0 + c1 + c2;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const size_t j = seg + (size_t)i * 64 + lane;
-        if (j < n) {
-            const unsigned digit = (unsigned)(k[i] >> shift) & 255u;
-            const size_t pos = (size_t)goff[digit] + cnt[w][digit] + loc[i];
-            keys_out[pos] = k[i];
-            vals_out[pos] = v[i];
-        }
-    }
 }
 
 __global__ void __launch_bounds__(256)
@@ -901,17 +785,9 @@ int pcp_grid_build(pcp_grid* g, const double* xyz, size_t n, double cell, const 
     hipLaunchKernelGGL(k_cell_keys, dim3(blocks_for(n, 256)), dim3(256), 0, s, d_xyz, n, cell, g->cmin[0], g->cmin[1],
                        g->cmin[2], k0, v0);
     GRID_TRY(hipEventRecord(g->ev1, s));
-    unsigned long long *kin = k0, *kout = k1;
-    unsigned *vin = v0, *vout = v1;
-    for (int p = 0; p < passes; ++p) {
-        const int shift = 8 * p;
-        hipLaunchKernelGGL(k_rs_hist, dim3(nblk), dim3(RS_THREADS), 0, s, kin, n, shift, hist, nblk);
-        hipLaunchKernelGGL(k_rs_scan, dim3(256), dim3(256), 0, s, hist, nblk, totals);
-        hipLaunchKernelGGL(k_rs_base, dim3(1), dim3(256), 0, s, totals, base);
-        hipLaunchKernelGGL(k_rs_scatter, dim3(nblk), dim3(RS_THREADS), 0, s, kin, vin, n, shift, hist, base, nblk, kout, vout);
-        std::swap(kin, kout);
-        std::swap(vin, vout);
-    }
+    unsigned long long* kin = nullptr;
+    unsigned* vin = nullptr;
+    radix_sort_pairs(s, k0, k1, v0, v1, n, 8 * passes, hist, totals, base, &kin, &vin);
     GRID_TRY(hipEventRecord(g->ev2, s));
     GRID_TRY(hipGetLastError());
     // occupied cells -> hash table

@@ -7,11 +7,16 @@
 //   stage   int[max_staging][max_points]   staged rows, never cleared between calls
 //   unknown int[1 + n]         [0] = count, then ids of points whose voxel is not in the table
 #include <hip/hip_runtime.h>
+#include <limits.h>
 #include <stdint.h>
 
+#include <algorithm>
+
 #include "../../include/pcp.h"
+#include "pcp_compact.h"
 #include "pcp_ctx.h"
 #include "pcp_host.h"
+#include "pcp_sort.h"
 
 struct pcp_voxel_state {
     int4* table = nullptr;   int table_rows = 0, table_valid = 0;   // capacity / rows of the last upload
@@ -21,11 +26,23 @@ struct pcp_voxel_state {
     int* unknown = nullptr;  int unknown_cap = 0;
     float4* pts = nullptr;   float4* debug = nullptr;   int pts_cap = 0;
     int* counter = nullptr;  // 16 ints
+    // state of the last pcp_voxelize call, consumed by pcp_voxel_insert_unknown
+    int last_n = 0, last_begin = 0, last_unknown = -1, last_stored = 0;
+    float last_size = 0.0f;
+    // scratch of the insertion
+    int4* table2 = nullptr;  int table2_rows = 0;
+    unsigned char* flag = nullptr;
+    unsigned long long *k0 = nullptr, *k1 = nullptr;
+    unsigned *v0 = nullptr, *v1 = nullptr, *heads = nullptr, *hist = nullptr, *totals = nullptr, *base = nullptr,
+             *counts = nullptr;
+    int ins_cap = 0;
+    int* mm = nullptr;       // 8 ints: coordinate range of the unknown points
 };
 
 void pcp_voxel_state_free(pcp_voxel_state* v) {
     if (!v) return;
-    void* bufs[] = {v->table, v->data, v->stat, v->stat_in, v->stage, v->unknown, v->pts, v->debug, v->counter};
+    void* bufs[] = {v->table, v->data, v->stat, v->stat_in, v->stage, v->unknown, v->pts, v->debug, v->counter,
+                    v->table2, v->flag, v->k0, v->k1, v->v0, v->v1, v->heads, v->hist, v->totals, v->base, v->counts, v->mm};
     for (void* p : bufs)
         if (p) (void)hipFree(p);
     delete v;
@@ -193,6 +210,143 @@ k_voxel_stage(const int4* __restrict__ table, int stored, const int* __restrict_
     }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Creation of new voxels on the device (the host half of Voxelizer.storeUnknownPoints,
+// Voxelizer.py:170-306): the points the last dispatch found no voxel for are grouped by
+// voxel coordinate in lexicographic order, every group becomes a voxel whose data row is
+// numbered stored + rank, holds the count of ALL its points and the ids of the first
+// max_points - 1 of them (ascending ids), and the new entries are merged into the sorted table.
+// ------------------------------------------------------------------------------------------
+
+__device__ __forceinline__ int3 voxel_coord(const float4 p, const float voxel_size) {
+    return make_int3((int)ceilf(p.x / voxel_size), (int)ceilf(p.y / voxel_size), (int)ceilf(p.z / voxel_size));
+}
+
+__global__ void k_mark_unknown(const int* __restrict__ unknown, int count, int begin_index, unsigned char* __restrict__ flag) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < count) flag[unknown[1 + j] - begin_index] = 1;
+}
+
+__global__ void __launch_bounds__(256)
+k_unknown_range(const float4* __restrict__ pts, const unsigned char* __restrict__ flag, int n, float voxel_size,
+                int* __restrict__ mm) {
+    int lo[3] = {INT_MAX, INT_MAX, INT_MAX}, hi[3] = {INT_MIN, INT_MIN, INT_MIN};
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        if (!flag[i]) continue;
+        const int3 c = voxel_coord(pts[i], voxel_size);
+        lo[0] = min(lo[0], c.x); hi[0] = max(hi[0], c.x);
+        lo[1] = min(lo[1], c.y); hi[1] = max(hi[1], c.y);
+        lo[2] = min(lo[2], c.z); hi[2] = max(hi[2], c.z);
+    }
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1)
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            lo[a] = min(lo[a], __shfl_down(lo[a], s, 64));
+            hi[a] = max(hi[a], __shfl_down(hi[a], s, 64));
+        }
+    if ((threadIdx.x & 63) == 0)
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            atomicMin(&mm[a], lo[a]);
+            atomicMax(&mm[3 + a], hi[a]);
+        }
+}
+
+struct IsUnknown {
+    const unsigned char* flag;
+    __device__ bool operator()(size_t i) const { return flag[i] != 0; }
+};
+
+// Emits (lexicographic key relative to the range's corner, global point id) in point order.
+struct EmitKey {
+    const float4* pts;
+    float voxel_size;
+    int mx, my, mz, bits, begin_index;
+    unsigned long long* keys;
+    unsigned* vals;
+    __device__ void operator()(size_t i, size_t slot) const {
+        const int3 c = voxel_coord(pts[i], voxel_size);
+        keys[slot] = ((unsigned long long)(unsigned)(c.x - mx) << (2 * bits)) |
+                     ((unsigned long long)(unsigned)(c.y - my) << bits) | (unsigned long long)(unsigned)(c.z - mz);
+        vals[slot] = (unsigned)(begin_index + (int)i);
+    }
+};
+
+struct IsHead {
+    const unsigned long long* keys;
+    __device__ bool operator()(size_t j) const { return j == 0 || keys[j] != keys[j - 1]; }
+};
+struct EmitHead {
+    unsigned* heads;
+    __device__ void operator()(size_t j, size_t slot) const { heads[slot] = (unsigned)j; }
+};
+
+__device__ __forceinline__ int lex_cmp(const int x0, const int y0, const int z0, const int4 b) {
+    if (x0 != b.x) return x0 < b.x ? -1 : 1;
+    if (y0 != b.y) return y0 < b.y ? -1 : 1;
+    if (z0 != b.z) return z0 < b.z ? -1 : 1;
+    return 0;
+}
+
+__device__ __forceinline__ int3 key_coord(const unsigned long long key, const int bits, const int mx, const int my, const int mz) {
+    const unsigned long long mask = (1ull << bits) - 1ull;
+    return make_int3((int)((key >> (2 * bits)) & mask) + mx, (int)((key >> bits) & mask) + my, (int)(key & mask) + mz);
+}
+
+// One wave per new voxel: data row stored + k = [count, first max_points-1 ids]; lane 0 also
+// places the voxel's table entry at k + (number of old entries below it).
+__global__ void __launch_bounds__(256)
+k_new_voxels(const unsigned long long* __restrict__ keys, const unsigned* __restrict__ vals, const unsigned* __restrict__ heads,
+             int n_new, int n_unknown, int bits, int mx, int my, int mz, const int4* __restrict__ table, int stored,
+             int4* __restrict__ table_out, int* __restrict__ data, int max_points, int* __restrict__ clash) {
+    const int k = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    if (k >= n_new) return;
+    const unsigned h = heads[k];
+    const unsigned end = (k + 1 < n_new) ? heads[k + 1] : (unsigned)n_unknown;
+    const int count = (int)(end - h);
+    const int row = stored + k;
+    int* out = data + (size_t)row * max_points;
+    if (lane == 0) out[0] = count;
+    const int keep = min(count, max_points - 1);
+    for (int j = lane; j < keep; j += 64) out[1 + j] = (int)vals[h + j];
+    for (int j = keep + lane; j < max_points - 1; j += 64) out[1 + j] = 0;
+    if (lane == 0) {
+        const int3 c = key_coord(keys[h], bits, mx, my, mz);
+        int lo = 0, hi = stored;                       // first old entry not below c
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            const int cmp = lex_cmp(c.x, c.y, c.z, table[mid]);
+            if (cmp == 0) *clash = 1;
+            if (cmp > 0) lo = mid + 1; else hi = mid;
+        }
+        table_out[k + lo] = make_int4(c.x, c.y, c.z, row);
+    }
+}
+
+// Old entry i moves to i + (number of new voxels below it).
+__global__ void __launch_bounds__(256)
+k_shift_old(const int4* __restrict__ table, int stored, const unsigned long long* __restrict__ keys,
+            const unsigned* __restrict__ heads, int n_new, int bits, int mx, int my, int mz, int4* __restrict__ table_out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= stored) return;
+    const int4 e = table[i];
+    int lo = 0, hi = n_new;                            // first new voxel not below e
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        const int3 c = key_coord(keys[heads[mid]], bits, mx, my, mz);
+        if (lex_cmp(c.x, c.y, c.z, e) < 0) lo = mid + 1; else hi = mid;
+    }
+    table_out[i + lo] = e;
+}
+
+__global__ void k_gather_counts(const int* __restrict__ data, int first_row, int n_rows, int max_points, int* __restrict__ out) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n_rows) out[k] = data[(size_t)(first_row + k) * max_points];
+}
+
 int use(pcp_ctx* c) {
     if (!c) return pcp_fail("null context");
     PCP_CHECK(hipSetDevice(c->device));
@@ -310,10 +464,174 @@ int pcp_voxelize(pcp_ctx* c, const float* pts_xyzw, int n, float voxel_size, int
     PCP_CHECK(hipMemcpyAsync(&count, v->unknown, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     PCP_CHECK(hipStreamSynchronize(c->stream));
     if (count < 0 || count > n) return pcp_fail("corrupt unknown count %d", count);
+    v->last_n = n; v->last_begin = begin_index; v->last_unknown = count; v->last_stored = stored; v->last_size = voxel_size;
     for (int i = 0; i < unknown_len; ++i) unknown[i] = 0;       // the reference uploads a zeroed list (:855, :881-883)
     PCP_CHECK(hipMemcpyAsync(unknown, v->unknown, (size_t)(1 + count) * sizeof(int), hipMemcpyDeviceToHost, c->stream));
     if (debug) PCP_CHECK(hipMemcpyAsync(debug, v->debug, (size_t)n * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
     PCP_CHECK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int pcp_voxel_reset(pcp_ctx* c) {
+    if (int e = use(c)) return e;
+    pcp_voxel_state* v = c->vox;
+    PCP_CHECK(hipStreamSynchronize(c->stream));
+    if (v->table) PCP_CHECK(hipFree(v->table));
+    if (v->data) PCP_CHECK(hipFree(v->data));
+    v->table = nullptr; v->table_rows = v->table_valid = 0;
+    v->data = nullptr;  v->data_rows = v->data_width = 0;
+    v->last_unknown = -1;
+    return 0;
+}
+
+int pcp_voxel_reserve(pcp_ctx* c, int rows, int max_points) {
+    if (int e = use(c)) return e;
+    pcp_voxel_state* v = c->vox;
+    if (rows < 1 || max_points < 2) return pcp_fail("bad sizes");
+    if (v->data && max_points != v->data_width) return pcp_fail("resident voxel data has row width %d", v->data_width);
+    PCP_CHECK(hipStreamSynchronize(c->stream));
+    if (rows > v->table_rows) {
+        int4* t = nullptr;
+        PCP_CHECK(hipMalloc(&t, (size_t)rows * sizeof(int4)));
+        if (v->table && v->table_valid)
+            PCP_CHECK(hipMemcpy(t, v->table, (size_t)v->table_valid * sizeof(int4), hipMemcpyDeviceToDevice));
+        if (v->table) PCP_CHECK(hipFree(v->table));
+        v->table = t;
+        v->table_rows = rows;
+    }
+    if (rows > v->data_rows) {
+        int* d = nullptr;
+        PCP_CHECK(hipMalloc(&d, (size_t)rows * max_points * sizeof(int)));
+        if (v->data && v->data_rows)
+            PCP_CHECK(hipMemcpy(d, v->data, (size_t)v->data_rows * max_points * sizeof(int), hipMemcpyDeviceToDevice));
+        PCP_CHECK(hipMemset(d + (size_t)v->data_rows * max_points, 0,
+                            (size_t)(rows - v->data_rows) * max_points * sizeof(int)));
+        if (v->data) PCP_CHECK(hipFree(v->data));
+        v->data = d;
+        v->data_rows = rows;
+        v->data_width = max_points;
+    }
+    return 0;
+}
+
+int pcp_voxel_insert_unknown(pcp_ctx* c, int max_points, int* new_stored, int* rows_capacity) {
+    if (int e = use(c)) return e;
+    pcp_voxel_state* v = c->vox;
+    if (!new_stored) return pcp_fail("new_stored is null");
+    if (v->last_unknown < 0) return pcp_fail("no dispatch to take unknown points from (pcp_voxelize first)");
+    const int n = v->last_n, U = v->last_unknown, stored = v->last_stored, begin = v->last_begin;
+    v->last_unknown = -1;                                // one insertion per dispatch
+    *new_stored = stored;
+    if (rows_capacity) *rows_capacity = v->data_rows;
+    if (U == 0) return 0;
+    if (stored > 0 && max_points != v->data_width) return pcp_fail("resident voxel data has row width %d", v->data_width);
+    hipStream_t s = c->stream;
+    // scratch
+    if (n > v->ins_cap) {
+        PCP_CHECK(hipStreamSynchronize(s));
+        for (void* p : {(void*)v->flag, (void*)v->k0, (void*)v->k1, (void*)v->v0, (void*)v->v1, (void*)v->heads,
+                        (void*)v->hist, (void*)v->counts})
+            if (p) PCP_CHECK(hipFree(p));
+        v->flag = nullptr; v->k0 = v->k1 = nullptr; v->v0 = v->v1 = v->heads = v->hist = v->counts = nullptr;
+        v->ins_cap = 0;
+        const size_t cap = (size_t)n;
+        PCP_CHECK(hipMalloc(&v->flag, cap));
+        PCP_CHECK(hipMalloc(&v->k0, cap * 8));
+        PCP_CHECK(hipMalloc(&v->k1, cap * 8));
+        PCP_CHECK(hipMalloc(&v->v0, cap * 4));
+        PCP_CHECK(hipMalloc(&v->v1, cap * 4));
+        PCP_CHECK(hipMalloc(&v->heads, cap * 4));
+        PCP_CHECK(hipMalloc(&v->hist, pcp::radix_hist_elems(cap) * 4));
+        PCP_CHECK(hipMalloc(&v->counts, pcp::compact_count_elems(cap) * 4));
+        v->ins_cap = n;
+    }
+    if (!v->totals) {
+        PCP_CHECK(hipMalloc(&v->totals, 256 * 4));
+        PCP_CHECK(hipMalloc(&v->base, 256 * 4));
+        PCP_CHECK(hipMalloc(&v->mm, 8 * 4));
+    }
+    // which points, and the range of their voxel coordinates
+    PCP_CHECK(hipMemsetAsync(v->flag, 0, (size_t)n, s));
+    hipLaunchKernelGGL(k_mark_unknown, dim3(cdiv(U, 256)), dim3(256), 0, s, v->unknown, U, begin, v->flag);
+    const int init[8] = {INT_MAX, INT_MAX, INT_MAX, INT_MIN, INT_MIN, INT_MIN, 0, 0};
+    PCP_CHECK(hipMemcpyAsync(v->mm, init, sizeof(init), hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_unknown_range, dim3(std::min(cdiv(n, 256), 1024)), dim3(256), 0, s, v->pts, v->flag, n,
+                       v->last_size, v->mm);
+    int mm[8];
+    PCP_CHECK(hipMemcpyAsync(mm, v->mm, sizeof(mm), hipMemcpyDeviceToHost, s));
+    PCP_CHECK(hipStreamSynchronize(s));
+    int bits = 1;
+    for (int a = 0; a < 3; ++a) {
+        if (mm[a] < -(1 << 20) || mm[3 + a] > (1 << 20)) return pcp_fail("voxel coordinate beyond +-2^20");
+        while ((1ll << bits) < (long long)mm[3 + a] - mm[a] + 1) ++bits;
+    }
+    // (key, id) in point order, stable sort by key, group heads
+    const EmitKey emit{v->pts, v->last_size, mm[0], mm[1], mm[2], bits, begin, v->k0, v->v0};
+    pcp::compact_ordered(s, IsUnknown{v->flag}, emit, (size_t)n, v->counts);
+    unsigned long long* keys = nullptr;
+    unsigned* vals = nullptr;
+    pcp::radix_sort_pairs(s, v->k0, v->k1, v->v0, v->v1, (size_t)U, 3 * bits, v->hist, v->totals, v->base, &keys, &vals);
+    pcp::compact_ordered(s, IsHead{keys}, EmitHead{v->heads}, (size_t)U, v->counts);
+    PCP_CHECK(hipGetLastError());
+    unsigned n_new = 0;
+    PCP_CHECK(hipMemcpyAsync(&n_new, v->counts + pcp::compact_tiles((size_t)U), 4, hipMemcpyDeviceToHost, s));
+    PCP_CHECK(hipStreamSynchronize(s));
+    if (n_new < 1 || n_new > (unsigned)U) return pcp_fail("corrupt voxel group count %u", n_new);
+    const int total = stored + (int)n_new;
+    // capacity: the host rule (double while new_stored >= rows, Voxelizer.py:238-252)
+    int rows = std::max(v->data_rows, 4096);
+    while (total >= rows) rows *= 2;
+    if (int e = pcp_voxel_reserve(c, rows, max_points)) return e;
+    if (rows > v->table2_rows) {
+        PCP_CHECK(hipStreamSynchronize(s));
+        if (v->table2) PCP_CHECK(hipFree(v->table2));
+        v->table2 = nullptr;
+        PCP_CHECK(hipMalloc(&v->table2, (size_t)rows * sizeof(int4)));
+        v->table2_rows = rows;
+    }
+    PCP_CHECK(hipMemsetAsync(v->mm + 7, 0, 4, s));
+    hipLaunchKernelGGL(k_new_voxels, dim3(cdiv((int)n_new * 64, 256)), dim3(256), 0, s, keys, vals, v->heads, (int)n_new, U,
+                       bits, mm[0], mm[1], mm[2], v->table, stored, v->table2, v->data, max_points, v->mm + 7);
+    if (stored > 0)
+        hipLaunchKernelGGL(k_shift_old, dim3(cdiv(stored, 256)), dim3(256), 0, s, v->table, stored, keys, v->heads,
+                           (int)n_new, bits, mm[0], mm[1], mm[2], v->table2);
+    PCP_CHECK(hipGetLastError());
+    int clash = 0;
+    PCP_CHECK(hipMemcpyAsync(&clash, v->mm + 7, 4, hipMemcpyDeviceToHost, s));
+    PCP_CHECK(hipStreamSynchronize(s));
+    if (clash) return pcp_fail("an unknown point's voxel is already in the table");      // Voxelizer.py:228-229
+    std::swap(v->table, v->table2);
+    std::swap(v->table_rows, v->table2_rows);
+    v->table_valid = total;
+    *new_stored = total;
+    if (rows_capacity) *rows_capacity = v->data_rows;
+    return 0;
+}
+
+int pcp_voxel_index_read(pcp_ctx* c, int rows, int32_t* voxel_index) {
+    if (int e = use(c)) return e;
+    pcp_voxel_state* v = c->vox;
+    if (rows == 0) return 0;
+    if (!voxel_index || rows < 0 || rows > v->table_valid) return pcp_fail("%d rows requested, %d resident", rows, v->table_valid);
+    PCP_CHECK(hipMemcpyAsync(voxel_index, v->table, (size_t)rows * sizeof(int4), hipMemcpyDeviceToHost, c->stream));
+    PCP_CHECK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int pcp_voxel_counts_read(pcp_ctx* c, int first_row, int n_rows, int32_t* counts) {
+    if (int e = use(c)) return e;
+    pcp_voxel_state* v = c->vox;
+    if (n_rows == 0) return 0;
+    if (!counts || first_row < 0 || n_rows < 0 || first_row + n_rows > v->data_rows) return pcp_fail("bad row range");
+    int* tmp = nullptr;
+    PCP_CHECK(hipMalloc(&tmp, (size_t)n_rows * 4));
+    hipLaunchKernelGGL(k_gather_counts, dim3(cdiv(n_rows, 256)), dim3(256), 0, c->stream, v->data, first_row, n_rows,
+                       v->data_width, tmp);
+    hipError_t e1 = hipMemcpyAsync(counts, tmp, (size_t)n_rows * 4, hipMemcpyDeviceToHost, c->stream);
+    hipError_t e2 = hipStreamSynchronize(c->stream);
+    (void)hipFree(tmp);
+    PCP_CHECK(e1);
+    PCP_CHECK(e2);
     return 0;
 }
 

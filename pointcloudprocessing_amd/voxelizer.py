@@ -1,13 +1,18 @@
 """Host side of the voxel map with the reference's call surface (Voxelizer.py,
 class Voxelizer; file:line citations point there).
 
-Division of labour is the reference's: the device appends the points of a new
-cloud to the voxels already in the table (ComputeShader.prepareDispatchVoxelizer)
-and runs the static/dynamic filter (prepareDispatchVoxelStager); voxels that do
-not exist yet are created here, on the host.  Where the reference inserts new
-voxels one at a time in a Python loop (an O(M) shift of the sorted table per
-voxel, :199-255), this class merges the whole batch into the table with one
-sorted insert; table, data-row numbering, counts and id sets come out the same.
+The device appends the points of a new cloud to the voxels already in the table
+(ComputeShader.prepareDispatchVoxelizer) and runs the static/dynamic filter
+(prepareDispatchVoxelStager), as in the reference.  Voxels that do not exist yet
+are created by the reference on the host, one at a time in a Python loop (an O(M)
+shift of the sorted table per voxel, :199-255) followed by a re-upload of table
+and rows; with this package's ComputeShader they are created on the device as well
+(insertUnknownVoxels) and only the table and the new rows' counts come back to the
+host arrays.  Table, data-row numbering, counts and id sets come out the same.
+The host arrays' point ids are then as stale as the reference's are for appended
+points: refreshVoxelData() (or any getter of stored ids) reads them back.
+When another compute object is injected (e.g. the reference's own), the batch
+merge below runs on the host instead.
 """
 import numpy as np
 
@@ -48,6 +53,10 @@ class Voxelizer:
         self.initVoxels()
         self.last_run_realloc = None
         self.voxel_size = np.array([voxel_size]).astype(np.float32)
+        self._rows_stale = False
+        if hasattr(self.compute, "voxelReserve"):
+            self.compute.voxelReserve(len(self.voxel_index), self.max_points)
+            self.realloc_needed = False
         self.inited = True
 
     def initVoxels(self, init_size=100):
@@ -92,6 +101,11 @@ class Voxelizer:
     def refreshVoxelData(self):
         if not self.last_run_realloc:
             self.compute.getFullVoxelData(self.stored_voxels, self.max_points, self.voxel_data)
+            self._rows_stale = False
+
+    def _fresh_rows(self):
+        if getattr(self, "_rows_stale", False):
+            self.refreshVoxelData()
 
     def stageAllRemaningVoxels(self, ui=None):
         """:139-165 -- stage until nothing comes back, then ten flush passes (a voxel
@@ -142,6 +156,16 @@ class Voxelizer:
         n = int(unknown_points[0])
         prev_stored = self.stored_voxels
         if n == 0:
+            return False, prev_stored
+        if hasattr(self.compute, "insertUnknownVoxels"):
+            new_stored, _ = self.compute.insertUnknownVoxels(self.max_points)
+            while new_stored >= len(self.voxel_index):
+                self._grow()                       # host arrays only: the device grew its own
+            self.compute.readVoxelIndex(new_stored, self.voxel_index)
+            self.voxel_data[prev_stored:new_stored, 0] = self.compute.readVoxelCounts(prev_stored,
+                                                                                      new_stored - prev_stored)
+            self._rows_stale = True
+            self.stored_voxels = new_stored
             return False, prev_stored
         ids = np.sort(unknown_points[1:n + 1])     # the device appends in no particular order
         coords = self.vectorizedGetVoxelCoord(self.added_points[ids][:, :3])
@@ -261,22 +285,26 @@ class Voxelizer:
 
     # ------------------------------------------------------------------ getters (:379-380, :573-630)
     def getVoxelDensities(self):
+        self._fresh_rows()
         return self.voxel_data[:, 0]
 
     def getStoredCount(self, voxel_data_index):
         if voxel_data_index >= self.stored_voxels:
             return None
+        self._fresh_rows()
         return self.voxel_data[voxel_data_index][0]
 
     def getStoredPointIndicies(self, voxel_data_index):
         if voxel_data_index >= self.stored_voxels:
             return None
+        self._fresh_rows()
         stored = self.voxel_data[voxel_data_index][0]
         return self.voxel_data[voxel_data_index][1:min(stored, self.max_points)]
 
     def getStoredPoints(self, voxel_data_index):
         if voxel_data_index >= self.stored_voxels:
             return None
+        self._fresh_rows()
         stored = self.voxel_data[voxel_data_index][0]
         ids = self.voxel_data[voxel_data_index][1:min(stored + 1, self.max_points)]
         return self.added_points[ids][:, :3]

@@ -4,6 +4,7 @@ the known answers of the reference's tests/VoxelizerTest.py.  Voxel coordinates,
 table positions, counts and counters are exact; point ids inside a row and rows
 in the staging buffer are compared as sets (append order is not defined by the
 reference either, tests/VoxelizerTest.py:325-331)."""
+import ctypes as C
 import hashlib
 
 import numpy as np
@@ -225,3 +226,76 @@ def test_voxel_error_paths(compute):
         compute.prepareDispatchVoxelStager(None, 3, 1024, st, True)                          # stored > table rows
     with pytest.raises(PcpError):
         compute.prepareDispatchVoxelizer(np.zeros((0, 3)), vi, vd, np.array([0.5], np.float32), 2, 0, 1024, True, -1)
+
+
+class _HostMergeCompute:
+    """This package's ComputeShader minus the device-side voxel creation: the Voxelizer then merges new
+    voxels on the host (the path taken with a foreign compute object)."""
+    def __init__(self, compute):
+        self._c = compute
+
+    def __getattr__(self, name):
+        if name in ("insertUnknownVoxels", "voxelReserve", "readVoxelIndex", "readVoxelCounts"):
+            raise AttributeError(name)
+        return getattr(self._c, name)
+
+
+def test_device_side_voxel_creation_equals_the_host_merge(compute):
+    """Three clouds: growth past the initial 4096 rows, voxels with more than 1023 points (the lowest ids
+    are kept), later clouds that add to old voxels and create new ones between them."""
+    rng = np.random.default_rng(8)
+    clouds = [rng.uniform(-22, 22, (60000, 3)) * [1, 0.1, 1],
+              np.vstack([rng.normal(0, 0.1, (3000, 3)) + [5.2, 0.2, -3.2], rng.uniform(-30, 30, (20000, 3)) * [1, 0.12, 1]]),
+              rng.uniform(-35, 35, (50000, 3)) * [1, 0.15, 1]]
+    maps = []
+    for comp in (compute, _HostMergeCompute(compute)):
+        v = Voxelizer(comp, None)
+        v.init(0.5)
+        v.filter_outliers = False
+        for c in clouds:
+            v.addPoints(c, None)
+        v.refreshVoxelData()
+        maps.append(v)
+    dev, host = maps
+    s = dev.stored_voxels
+    assert s == host.stored_voxels and s > 8192 and len(dev.voxel_index) == len(host.voxel_index)
+    assert np.array_equal(dev.voxel_index[:s], host.voxel_index[:s])
+    assert np.array_equal(dev.voxel_data[:s, 0], host.voxel_data[:s, 0])
+    assert dev.voxel_data[:s, 0].max() > 1023 and dev.voxel_data[:s, 0].sum() == sum(len(c) for c in clouds)
+    for r in range(s):
+        k = min(dev.voxel_data[r, 0], dev.max_points - 1)
+        a, b = np.sort(dev.voxel_data[r, 1:1 + k]), np.sort(host.voxel_data[r, 1:1 + k])
+        created_whole = dev.voxel_data[r, 0] < dev.max_points          # rows that overflowed later keep arbitrary ids
+        if created_whole:
+            assert np.array_equal(a, b)
+    big = int(np.argmax(dev.voxel_data[:s, 0]))
+    assert dev.getStoredPoints(big).shape == (dev.max_points - 1, 3)
+    # a voxel CREATED with more points than a row holds keeps the lowest ids, in order (both paths)
+    blob = np.vstack([rng.uniform(-3, 3, (500, 3)), rng.uniform(0.01, 0.49, (3000, 3)) + [4.0, 1.0, -2.0]])
+    blob = blob[rng.permutation(len(blob))]
+    rows = []
+    for comp in (compute, _HostMergeCompute(compute)):
+        v = Voxelizer(comp, None)
+        v.init(0.5)
+        v.filter_outliers = False
+        v.addPoints(blob, None)
+        if comp is compute:
+            v.refreshVoxelData()      # host-merged rows are only on the host until the next dispatch uploads them
+        r = int(np.argmax(v.voxel_data[:v.stored_voxels, 0]))
+        assert v.voxel_data[r, 0] == 3000
+        rows.append(v.voxel_data[r, 1:v.max_points].copy())
+    inside = np.nonzero(np.all(np.ceil(blob.astype(np.float32) / np.float32(0.5)) == [9, 3, -3], axis=1))[0]
+    assert np.array_equal(rows[0], inside[:1023]) and np.array_equal(rows[1], inside[:1023])
+
+
+def test_voxel_insertion_error_paths(compute):
+    lib, ctx = compute._lib, compute._ctx
+    v = Voxelizer(compute, None)
+    v.init(1.0)
+    stored, cap = C.c_int(0), C.c_int(0)
+    assert lib.pcp_voxel_insert_unknown(ctx, 1024, C.byref(stored), C.byref(cap)) != 0      # no dispatch yet
+    v.addPoints(np.array([[0.5, 0.5, 0.5], [1.5, 0.5, 0.5], [0.5, 0.4, 0.3]]), None)
+    assert v.stored_voxels == 2 and sorted(v.voxel_data[:2, 0].tolist()) == [1, 2]
+    assert lib.pcp_voxel_insert_unknown(ctx, 1024, C.byref(stored), C.byref(cap)) != 0      # already consumed
+    with pytest.raises(RuntimeError):
+        v.addPoints(np.array([[3e6, 0.0, 0.0]]), None)                                        # beyond +-2^20 voxels
