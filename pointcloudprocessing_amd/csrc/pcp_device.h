@@ -58,12 +58,25 @@ __device__ __forceinline__ float4 unit_sphere(const float4 p, const float4 o) {
 // ring_lower_bound.
 #define PCP_AZ_FAR 0.0094050f
 
+// Arrays the search gathers from are addressed as GLOBAL memory explicitly: pointers that reach a
+// kernel through a descriptor in device memory are generic to the compiler, and generic (flat) loads
+// can neither use the scalar-base addressing mode nor skip the aperture check.
+#define PCP_GLOBAL __attribute__((address_space(1)))
+typedef float pcp_f4 __attribute__((ext_vector_type(4)));
+typedef const pcp_f4 PCP_GLOBAL* gf4_t;
+
+__device__ __forceinline__ gf4_t as_global(const float4* p) { return (gf4_t)(const void*)p; }
+__device__ __forceinline__ float4 ld4(const gf4_t p, const size_t i) {
+    const pcp_f4 v = p[i];
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+
 struct Target {
-    const float4* __restrict__ a;    // target points
-    const float4* __restrict__ ua;   // unit_sphere(a[i])
+    gf4_t a;                         // target points
+    gf4_t ua;                        // unit_sphere(a[i])
     const int2* scan;                // (begin, end_inclusive) per ring, in LDS
     const float4* stat;              // per ring (sin, cos) of its lowest and highest elevation, in LDS
-    const float4* __restrict__ bins; // [azimuth bin][ring]: the same for the ring's points in bins b-1, b, b+1
+    gf4_t bins;                      // [azimuth bin][ring]: the same for the ring's points in bins b-1, b, b+1
     int n_a;
     int Z;                           // lens_data.z
     float4 o;
@@ -86,7 +99,7 @@ __device__ __forceinline__ void ring_window(const Target& T, const float4 q, con
         // 2*CHECK window slots are the ring's single point.
         const int closest = beg + (beg + end) / 2;
         best = min(closest, T.n_a - 1);
-        const float d = distsq(q, T.a[beg]);
+        const float d = distsq(q, ld4(T.a, beg));
         if (d < mind && beg != exclude) { mind = d; best = beg; }
         return;
     }
@@ -96,8 +109,8 @@ __device__ __forceinline__ void ring_window(const Target& T, const float4 q, con
     for (int i = 0; i < runs; ++i) {
         const int i1 = (idx == 0) ? L - 1 : idx - 1;
         const int i2 = (idx + 1 == L) ? 0 : idx + 1;
-        const float c1 = dot4(T.ua[beg + i1], ref) + 1.0f;
-        const float c2 = dot4(T.ua[beg + i2], ref) + 1.0f;
+        const float c1 = dot4(ld4(T.ua, beg + i1), ref) + 1.0f;
+        const float c2 = dot4(ld4(T.ua, beg + i2), ref) + 1.0f;
         int t = (c1 > c2) ? idx - half : idx + half;
         t = (t < 0) ? t + L : ((t >= L) ? t - L : t);
         idx = t;
@@ -110,7 +123,7 @@ __device__ __forceinline__ void ring_window(const Target& T, const float4 q, con
             int t = idx + i;
             t = (t < 0) ? t + L : ((t >= L) ? t - L : t);
             const int test = beg + t;
-            const float d = distsq(q, T.a[test]);
+            const float d = distsq(q, ld4(T.a, test));
             if (d < mind && test != exclude) { mind = d; best = test; }
         }
     } else {
@@ -118,7 +131,7 @@ __device__ __forceinline__ void ring_window(const Target& T, const float4 q, con
             int t = (idx + i + L) % L;
             if (t < 0) t += L;
             const int test = beg + t;
-            const float d = distsq(q, T.a[test]);
+            const float d = distsq(q, ld4(T.a, test));
             if (d < mind && test != exclude) { mind = d; best = test; }
         }
     }
@@ -179,7 +192,7 @@ __device__ __forceinline__ int find_closest(const Target& T, const float4 q, flo
     const float sq = ref.y;
     const float cq = sqrtf(ref.x * ref.x + ref.z * ref.z + ref.w * ref.w);
     const bool can_prune = cq > 0.05f;          // near the pole the elevation is ill-conditioned
-    const float4* __restrict__ my_bins = T.bins + (size_t)az_bin(ref.x, ref.z) * T.Z;   // this query's row
+    const gf4_t my_bins = T.bins + (size_t)az_bin(ref.x, ref.z) * T.Z;   // this query's row
     const float far = (v.x * v.x + v.z * v.z) * PCP_AZ_FAR;
     float mind = PCP_BIG;
     int glob = 0, ring = -1;
@@ -209,7 +222,7 @@ __device__ __forceinline__ int find_closest(const Target& T, const float4 q, flo
         if (r < from || r >= to) continue;
         if (can_prune && mind < PCP_BIG) {
             if (ring_lower_bound(T.stat[r], sq, cq, rho2) > mind) continue;
-            if (ring_bin_lower_bound(my_bins[r], sq, cq, rho2, far) > mind) continue;
+            if (ring_bin_lower_bound(ld4(my_bins, r), sq, cq, rho2, far) > mind) continue;
         }
 #ifdef PCP_STATS
         {

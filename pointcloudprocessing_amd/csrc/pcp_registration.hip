@@ -149,7 +149,7 @@ k_nn(const float4* __restrict__ a, const float4* __restrict__ ua, const int2* __
     load_rings(smem, scan, stat, Z, s_scan, s_stat);
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const bool in = i < n_b;
-    const Target T{a, ua, s_scan, s_stat, bins, n_a, Z, o};
+    const Target T{as_global(a), as_global(ua), s_scan, s_stat, as_global(bins), n_a, Z, o};
     const float4 q = in ? b[i] : make_float4(0.f, 0.f, 0.f, 0.f);
     float h = in ? hint[i] : -1.0f;
     if (!in) return;
@@ -178,7 +178,7 @@ __device__ __forceinline__ void normals_body(const float4* __restrict__ a, const
     load_rings(smem, scan, stat, Z, s_scan, s_stat);
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_a) return;
-    const Target T{a, ua, s_scan, s_stat, nullptr, n_a, Z, o};
+    const Target T{as_global(a), as_global(ua), s_scan, s_stat, nullptr, n_a, Z, o};
     // getScanLineOfPoint, NormalShader.glsl:1-10: first ring that contains the point
     int ring = -1;
     for (int r = 0; r < Z; ++r) {
@@ -288,7 +288,7 @@ __device__ __forceinline__ void ls_body(const LsArgs& A, char* smem) {
             q = A.b32[i];
         }
     }
-    const Target T{a, A.ua, s_scan, s_stat, A.bins, A.n_a, A.Z, A.o};
+    const Target T{as_global(a), as_global(A.ua), s_scan, s_stat, as_global(A.bins), A.n_a, A.Z, A.o};
     int nn = in ? i : 0;      // debug_info.x >= 1: identity correspondences, LeastSquaresPoint.glsl:78-81
     float d = 0.0f;
     if (!debug) {
@@ -296,13 +296,13 @@ __device__ __forceinline__ void ls_body(const LsArgs& A, char* smem) {
         if (in) {
             nn = find_closest(T, q, h);
             hint[i] = h;
-            d = distsq(q, a[nn]);
+            d = distsq(q, ld4(T.a, nn));
         }
     }
     if (in) {
-        const float4 pa = a[nn];
+        const float4 pa = ld4(T.a, nn);
         if (MODE == PCP_MODE_POINT) ls_point_values(pa, q, d, v);
-        else ls_plane_values(pa, q, normals[nn], d, v);
+        else ls_plane_values(pa, q, ld4(as_global(normals), nn), d, v);
         if (tiles) {
             float* t = tiles + (size_t)i * 64;
 #pragma unroll
