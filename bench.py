@@ -3,8 +3,8 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-Workload (BASELINE.json configs[1], with the substitution its survey records
-because golden-tiger.ply is absent): a 64-ring 120k-point sweep registered
+Workload (the reference's point-to-plane registration of a KITTI-size frame pair; the
+golden-tiger.ply cloud its demo uses is not available, so the pair is built from a KITTI frame): a 64-ring 120k-point sweep registered
 against a rigidly moved, noise-perturbed copy of itself by point-to-plane ICP
 with ring normals, at most 10 iterations, stop at mean|dx| < 1e-6
 (PointcloudIcpContainer.full_pt2pl as UI.py:400 calls it).  One STEP = every
@@ -162,7 +162,7 @@ def main():
     batch.profile(False)
     avg_iters = float(np.mean(iters))
     # algorithmic bytes of one launch = 32 B per source point it processed + the 32 B per target
-    # point (point + normal) each pair reads once, spread over that pair's launches (DESIGN.md)
+    # point (point + normal) each pair reads once, spread over that pair's launches
     alg_bytes = (32.0 * ls_points + 32.0 * n_a * args.pairs * max(1, min(args.steps, 5))) / max(ls_launches, 1)
     avg_launch_s = ls_ms * 1e-3 / max(ls_launches, 1)
     achieved = alg_bytes / avg_launch_s / 1e9

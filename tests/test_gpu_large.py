@@ -1,4 +1,4 @@
-"""Full-size cases (BASELINE configs[2]: a 1M-point synthetic sweep): parity with the CPU
+"""Full-size cases (a 1M-point synthetic sweep): parity with the CPU
 restatement on a sample of the queries, and size-independent properties on all of them
 (hint-guided second pass reproduces the first, voxelization is idempotent and conserves
 points, the table stays sorted)."""

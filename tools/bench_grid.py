@@ -1,4 +1,4 @@
-"""Cell-grid leg (BASELINE configs[2]): 1M-point clouds, cell sizes 0.1-2.0 m: build (Morton radix
+"""Cell-grid leg: 1M-point clouds, cell sizes 0.1-2.0 m: build (Morton radix
 sort + cell hash) and exact self-query with 5 cm jitter.  Prints one line per case.
     python tools/bench_grid.py [n_points]"""
 import sys

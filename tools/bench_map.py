@@ -1,4 +1,4 @@
-"""Scan-to-map leg (BASELINE configs[4] on one GPU): a map tiled from synthetic sweeps along a straight
+"""Scan-to-map leg on one GPU: a map tiled from synthetic sweeps along a straight
 trajectory, one 120k-point scan registered against it (point-to-point, exact neighbours within 0.4 m).
     python tools/bench_map.py [n_sweeps]"""
 import os
