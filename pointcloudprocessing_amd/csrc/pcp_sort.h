@@ -10,9 +10,11 @@ namespace pcp {
 
 constexpr unsigned long long RS_EMPTY_KEY = 0xFFFFFFFFFFFFFFFFull;
 
-// LSD radix sort, 8 bits per pass, stable.  A block owns a tile of 2048 keys.
+// LSD radix sort, 8 bits per pass, stable.  A block of 4 waves owns a tile of RS_TILE keys, RS_ROUNDS
+// rounds of 64 per wave.  Larger tiles mean fewer per-block histograms to scan.
 constexpr int RS_THREADS = 256;
-constexpr int RS_TILE = 2048;
+constexpr int RS_ROUNDS = 16;
+constexpr int RS_TILE = RS_THREADS * RS_ROUNDS;
 
 static __global__ void __launch_bounds__(RS_THREADS)
 k_rs_hist(const unsigned long long* __restrict__ keys, size_t n, int shift, unsigned* __restrict__ hist, int nblk) {
@@ -66,7 +68,7 @@ static __global__ void __launch_bounds__(256) k_rs_base(const unsigned* __restri
     base[threadIdx.x] = s[threadIdx.x] - v;
 }
 
-// Each wave ranks its own 512 consecutive keys (8 rounds of 64, in order), so
+// Each wave ranks its own 64 * RS_ROUNDS consecutive keys (rounds of 64, in order), so
 // the rank of a key among equal digits is: digit base + blocks before + waves
 // before + earlier rounds of this wave + lower lanes of this round.
 static __global__ void __launch_bounds__(RS_THREADS)
@@ -79,11 +81,11 @@ k_rs_scatter(const unsigned long long* __restrict__ keys_in, const unsigned* __r
     for (int j = tid; j < 4 * 256; j += RS_THREADS) (&cnt[0][0])[j] = 0;
     goff[tid] = base[tid] + hist[(size_t)tid * nblk + blockIdx.x];
     __syncthreads();
-    unsigned long long k[8];
-    unsigned v[8], loc[8];
-    const size_t seg = (size_t)blockIdx.x * RS_TILE + (size_t)w * 512;
+    unsigned long long k[RS_ROUNDS];
+    unsigned v[RS_ROUNDS], loc[RS_ROUNDS];
+    const size_t seg = (size_t)blockIdx.x * RS_TILE + (size_t)w * (64 * RS_ROUNDS);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < RS_ROUNDS; ++i) {
         const size_t j = seg + (size_t)i * 64 + lane;
         const bool valid = j < n;
         k[i] = valid ? keys_in[j] : RS_EMPTY_KEY;
@@ -116,7 +118,7 @@ k_rs_scatter(const unsigned long long* __restrict__ keys_in, const unsigned* __r
     }
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < RS_ROUNDS; ++i) {
         const size_t j = seg + (size_t)i * 64 + lane;
         if (j < n) {
             const unsigned digit = (unsigned)(k[i] >> shift) & 255u;
