@@ -197,58 +197,119 @@ __device__ __forceinline__ double axis_gap(const double q, const double lo, cons
     return fmax(g, 0.0);
 }
 
+// Cells with more points than this are not scanned by the lane that meets them but handed to the
+// whole wave (grid_nn): a lane's serial walk through a crowded cell would otherwise set the time of
+// its wave, and with it of the launch.
+constexpr unsigned CROWDED = 96;
+constexpr int DEFER_SLOTS = 4;
+
+struct Deferred {              // crowded cells a lane met in the current shell
+    unsigned start[DEFER_SLOTS], count[DEFER_SLOTS];
+    double boxd2[DEFER_SLOTS];
+    int n;
+};
+
+__device__ __forceinline__ void take_point(const GridPoint& p, const unsigned j, const double qx, const double qy,
+                                           const double qz, double& best, long long& bid, int& bpos) {
+    const double dx = qx - p.x, dy = qy - p.y, dz = qz - p.z;
+    const double d2 = (dx * dx + dy * dy) + dz * dz;
+    if (d2 < best || (d2 == best && p.id < bid)) { best = d2; bid = p.id; bpos = (int)j; }
+}
+
 __device__ __forceinline__ void visit_cell(const GridView& G, const int x, const int y, const int z,
                                            const double qx, const double qy, const double qz,
-                                           double& best, long long& bid, int& bpos) {
+                                           double& best, long long& bid, int& bpos, Deferred& D) {
     // no point of the cell can be nearer than the cell's box
     const double gx = axis_gap(qx, (double)(x + G.cminx) * G.cell, (double)(x + G.cminx + 1) * G.cell, G.eps);
     const double gy = axis_gap(qy, (double)(y + G.cminy) * G.cell, (double)(y + G.cminy + 1) * G.cell, G.eps);
     const double gz = axis_gap(qz, (double)(z + G.cminz) * G.cell, (double)(z + G.cminz + 1) * G.cell, G.eps);
-    if ((gx * gx + gy * gy) + gz * gz > best) return;
+    const double boxd2 = (gx * gx + gy * gy) + gz * gz;
+    if (boxd2 > best) return;
     unsigned start, count;
     if (!find_cell(G.table, G.log_cap, morton3((unsigned)x, (unsigned)y, (unsigned)z), start, count)) return;
-    for (unsigned j = start; j < start + count; ++j) {
-        const GridPoint p = G.pts[j];
-        const double dx = qx - p.x, dy = qy - p.y, dz = qz - p.z;
-        const double d2 = (dx * dx + dy * dy) + dz * dz;
-        if (d2 < best || (d2 == best && p.id < bid)) { best = d2; bid = p.id; bpos = (int)j; }
+    if (count > CROWDED && D.n < DEFER_SLOTS) {
+#pragma unroll
+        for (int e = 0; e < DEFER_SLOTS; ++e)
+            if (e == D.n) { D.start[e] = start; D.count[e] = count; D.boxd2[e] = boxd2; }
+        ++D.n;
+        return;
     }
+    for (unsigned j = start; j < start + count; ++j) take_point(G.pts[j], j, qx, qy, qz, best, bid, bpos);
 }
 
-// best must hold the squared search radius (or +inf) on entry; only strictly
-// nearer points are accepted.  bid = -1 when nothing is.
-__device__ __forceinline__ void grid_nn(const GridView& G, const double qx, const double qy, const double qz,
-                                        double& best, long long& bid, int& bpos) {
+// Exact nearest map point of (qx, qy, qz).  EVERY lane of the wave must call this together (has =
+// this lane holds a query): the shells of cells are walked lane by lane, but the crowded cells a
+// shell turns up are scanned by all 64 lanes for one owner at a time.  best must hold the squared
+// search radius (or +inf) on entry; only strictly nearer points are accepted; bid = -1 when none is.
+__device__ __forceinline__ void grid_nn(const GridView& G, const bool has, const double qx, const double qy,
+                                        const double qz, double& best, long long& bid, int& bpos) {
+    const int lane = threadIdx.x & 63;
     bid = -1;
     bpos = -1;
-    if (G.n == 0) return;
     const int ax = cell_of(qx, G.cell), ay = cell_of(qy, G.cell), az = cell_of(qz, G.cell);
     const int cx = ax - G.cminx, cy = ay - G.cminy, cz = az - G.cminz;
     auto outside = [](int c, int e) { return c < 0 ? -c : (c > e - 1 ? c - (e - 1) : 0); };
     auto reach = [](int c, int e) { return max(c, e - 1 - c); };
-    const int k0 = max(outside(cx, G.ex), max(outside(cy, G.ey), outside(cz, G.ez)));
+    int k = max(outside(cx, G.ex), max(outside(cy, G.ey), outside(cz, G.ez)));
     const int k1 = max(reach(cx, G.ex), max(reach(cy, G.ey), reach(cz, G.ez)));
-    for (int k = k0; k <= k1; ++k) {
-        const int z0 = max(cz - k, 0), z1 = min(cz + k, G.ez - 1);
-        const int y0 = max(cy - k, 0), y1 = min(cy + k, G.ey - 1);
-        const int x0 = max(cx - k, 0), x1 = min(cx + k, G.ex - 1);
-        for (int z = z0; z <= z1; ++z) {
-            const bool zedge = (z == cz - k) || (z == cz + k);
-            for (int y = y0; y <= y1; ++y) {
-                if (zedge || y == cy - k || y == cy + k) {
-                    for (int x = x0; x <= x1; ++x) visit_cell(G, x, y, z, qx, qy, qz, best, bid, bpos);
-                } else {
-                    if (cx - k >= 0 && cx - k < G.ex) visit_cell(G, cx - k, y, z, qx, qy, qz, best, bid, bpos);
-                    if (cx + k >= 0 && cx + k < G.ex) visit_cell(G, cx + k, y, z, qx, qy, qz, best, bid, bpos);
+    bool live = has && G.n != 0 && k <= k1;
+    while (__any(live)) {
+        Deferred D;
+        D.n = 0;
+        if (live) {
+            const int z0 = max(cz - k, 0), z1 = min(cz + k, G.ez - 1);
+            const int y0 = max(cy - k, 0), y1 = min(cy + k, G.ey - 1);
+            const int x0 = max(cx - k, 0), x1 = min(cx + k, G.ex - 1);
+            for (int z = z0; z <= z1; ++z) {
+                const bool zedge = (z == cz - k) || (z == cz + k);
+                for (int y = y0; y <= y1; ++y) {
+                    if (zedge || y == cy - k || y == cy + k) {
+                        for (int x = x0; x <= x1; ++x) visit_cell(G, x, y, z, qx, qy, qz, best, bid, bpos, D);
+                    } else {
+                        if (cx - k >= 0 && cx - k < G.ex) visit_cell(G, cx - k, y, z, qx, qy, qz, best, bid, bpos, D);
+                        if (cx + k >= 0 && cx + k < G.ex) visit_cell(G, cx + k, y, z, qx, qy, qz, best, bid, bpos, D);
+                    }
                 }
             }
         }
-        // everything not yet visited lies outside the cube of cells [c-k, c+k]^3
-        const double mx = fmin(qx - (double)(ax - k) * G.cell, (double)(ax + k + 1) * G.cell - qx);
-        const double my = fmin(qy - (double)(ay - k) * G.cell, (double)(ay + k + 1) * G.cell - qy);
-        const double mz = fmin(qz - (double)(az - k) * G.cell, (double)(az + k + 1) * G.cell - qz);
-        const double m = fmin(mx, fmin(my, mz)) - G.eps;
-        if (m > 0.0 && best < m * m) break;
+        // crowded cells: one owner at a time, all lanes scan, the owner keeps the result
+        unsigned long long pending = __ballot(D.n > 0);
+        while (pending) {
+            const int owner = __ffsll((long long)pending) - 1;
+            pending &= pending - 1;
+            const int on = __shfl(D.n, owner, 64);
+            const double ox = __shfl(qx, owner, 64), oy = __shfl(qy, owner, 64), oz = __shfl(qz, owner, 64);
+#pragma unroll
+            for (int e = 0; e < DEFER_SLOTS; ++e) {
+                if (e >= on) break;                                        // wave-uniform
+                const double obest = __shfl(best, owner, 64);              // tightened by the entries before
+                if (__shfl(D.boxd2[e], owner, 64) > obest) continue;
+                const unsigned start = __shfl(D.start[e], owner, 64), count = __shfl(D.count[e], owner, 64);
+                double lb = obest;
+                long long lid = __shfl(bid, owner, 64);
+                int lpos = -1;
+                for (unsigned j = start + lane; j < start + count; j += 64)
+                    take_point(G.pts[j], j, ox, oy, oz, lb, lid, lpos);
+                if (lpos < 0) lb = INFINITY;                               // nothing better in this lane's share
+#pragma unroll
+                for (int sft = 32; sft > 0; sft >>= 1) {
+                    const double ob = __shfl_xor(lb, sft, 64);
+                    const long long oi = __shfl_xor(lid, sft, 64);
+                    const int op = __shfl_xor(lpos, sft, 64);
+                    if (ob < lb || (ob == lb && op >= 0 && (lpos < 0 || oi < lid))) { lb = ob; lid = oi; lpos = op; }
+                }
+                if (lane == owner && lpos >= 0) { best = lb; bid = lid; bpos = lpos; }
+            }
+        }
+        if (live) {
+            // everything not yet visited lies outside the cube of cells [c-k, c+k]^3
+            const double mx = fmin(qx - (double)(ax - k) * G.cell, (double)(ax + k + 1) * G.cell - qx);
+            const double my = fmin(qy - (double)(ay - k) * G.cell, (double)(ay + k + 1) * G.cell - qy);
+            const double mz = fmin(qz - (double)(az - k) * G.cell, (double)(az + k + 1) * G.cell - qz);
+            const double m = fmin(mx, fmin(my, mz)) - G.eps;
+            ++k;
+            if ((m > 0.0 && best < m * m) || k > k1) live = false;
+        }
     }
 }
 
@@ -256,11 +317,13 @@ __global__ void __launch_bounds__(256)
 k_grid_nn(const GridView G, const double* __restrict__ src, size_t m, double max_d2,
           double* __restrict__ nn_d, long long* __restrict__ nn_idx, int* __restrict__ nn_pos) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= m) return;
+    const bool has = i < m;
     double best = max_d2;
     long long bid;
     int bpos;
-    grid_nn(G, src[3 * i + 0], src[3 * i + 1], src[3 * i + 2], best, bid, bpos);
+    const size_t at = has ? i : 0;
+    grid_nn(G, has, src[3 * at + 0], src[3 * at + 1], src[3 * at + 2], best, bid, bpos);
+    if (!has) return;
     nn_d[i] = (bid >= 0) ? sqrt(best) : INFINITY;
     nn_idx[i] = bid;
     nn_pos[i] = bpos;
@@ -442,22 +505,27 @@ __global__ void __launch_bounds__(PCP_BLOCK) k_map_ls(const MapLsArgs A) {
     float v[PCP_NVAL];
 #pragma unroll
     for (int k = 0; k < PCP_NVAL; ++k) v[k] = 0.0f;
+    double px = 0.0, py = 0.0, pz = 0.0;
+    bool owned = false;
     if (in) {
-        double px = A.src[3 * i + 0], py = A.src[3 * i + 1], pz = A.src[3 * i + 2];
+        px = A.src[3 * i + 0]; py = A.src[3 * i + 1]; pz = A.src[3 * i + 2];
         if (st->pending) {
             const double nx = ((st->R[0] * px + st->R[1] * py) + st->R[2] * pz) - st->t[0];
             const double ny = ((st->R[3] * px + st->R[4] * py) + st->R[5] * pz) - st->t[1];
             const double nz = ((st->R[6] * px + st->R[7] * py) + st->R[8] * pz) - st->t[2];
             px = nx; py = ny; pz = nz;
+            A.src[3 * i + 0] = px; A.src[3 * i + 1] = py; A.src[3 * i + 2] = pz;
         }
-        if (st->pending) { A.src[3 * i + 0] = px; A.src[3 * i + 1] = py; A.src[3 * i + 2] = pz; }
         const unsigned long long key = morton3((unsigned)(cell_of(px, A.own_cell) + COORD_BIAS),
                                                (unsigned)(cell_of(py, A.own_cell) + COORD_BIAS),
                                                (unsigned)(cell_of(pz, A.own_cell) + COORD_BIAS));
-        long long bid = -1;
-        int bpos = -1;
-        double best = A.radius2;
-        if (key >= A.own_lo && key < A.own_hi) grid_nn(A.G, px, py, pz, best, bid, bpos);
+        owned = key >= A.own_lo && key < A.own_hi;
+    }
+    long long bid = -1;
+    int bpos = -1;
+    double best = A.radius2;
+    grid_nn(A.G, owned, px, py, pz, best, bid, bpos);          // the whole wave takes part
+    if (in) {
         if (A.nn_idx) { A.nn_idx[i] = bid; A.nn_d[i] = (bid >= 0) ? sqrt(best) : INFINITY; }
         if (bid >= 0) {
             const GridPoint p = A.G.pts[bpos];
