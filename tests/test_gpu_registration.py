@@ -305,3 +305,55 @@ def test_perturbed_kitti_frame_converges_like_the_reference_scenario(compute, pl
     assert np.abs(R_opt @ randrot - np.eye(3)).max() < tol_R
     assert np.abs(R_opt @ randtrans - t_opt).max() < tol_t
     assert np.median(err) < tol_p
+
+
+# ------------------------------------------------------------------------------ ragged ring layouts
+@pytest.mark.parametrize("seed", [0, 1, 2, 3])
+def test_ragged_ring_layouts_match_oracle_bitwise(compute, seed):
+    """Arbitrary ring tables, not a LiDAR's: rings of 1 to 60 points (shorter than the +-10 window, of
+    length 1, of length a power of two), points the rings do not cover, points near the sensor's pole,
+    a non-zero origin.  NN, hints, normals and both tile sums against the restatement, bit for bit."""
+    rng = np.random.default_rng(100 + seed)
+    lengths = list(rng.integers(1, 61, 30)) + [1, 2, 8, 16, 32, 64, 19, 20, 21]
+    rng.shuffle(lengths)
+    gaps = rng.integers(0, 3, len(lengths))                       # a few points between rings belong to none
+    lines, pos = [], 0
+    for L, gp in zip(lengths, gaps):
+        pos += int(gp)
+        lines.append((pos, pos + int(L) - 1))
+        pos += int(L)
+    n_a = pos + 5
+    a = rng.normal(0, 6, (n_a, 3))
+    a[::37] = [0.0, 9.0, 0.0] + rng.normal(0, 0.02, (len(a[::37]), 3))      # almost straight above the sensor
+    a[5] = a[4]                                                               # duplicate neighbours
+    b = np.vstack([a[rng.integers(0, n_a, 300)] + rng.normal(0, 0.05, (300, 3)), rng.normal(0, 8, (150, 3)),
+                   [[0.0, 0.127, 0.0]], [[1e-7, 40.0, -1e-7]]])
+    origin = np.array([0.4, -0.2, 0.1]) if seed % 2 else np.zeros(3)
+    # nearest neighbour, three passes (all rings, then hinted)
+    st = O.RingIcp(100)
+    st.prepare_nns(a, lines, origin)
+    compute.prepareNNS(a, lines, b, origin)
+    for call in range(3):
+        idx, dist = compute.dispatchNNS(b)
+        ridx, rdist = st.dispatch_nns(b)
+        assert np.array_equal(idx, ridx), f"call {call}"
+        assert np.array_equal(bits(dist), bits(rdist)), f"call {call}"
+        assert np.array_equal(bits(compute.corr_out[:, 3]), bits(st.hint)), f"call {call}"
+    # normals
+    compute.prepareDispatchNormals(a, lines, origin)
+    a4, o4 = O.pad_points(a), O.origin4(origin)
+    ref_n = O.normals(a4, o4, O.pad_scan_lines(lines).astype(np.int64), 100)
+    assert np.array_equal(bits(compute.normals_out_a[:n_a]), bits(ref_n))
+    # tile sums, unpadded (point) and padded (plane) ring tables
+    sp = O.RingIcp(100)
+    sp.prepare_ls(a, lines, origin)
+    compute.prepareLS(a, lines, b, origin)
+    H, bb = compute.dispatchLS(b)
+    rH, rb = sp.dispatch_ls(b)
+    assert np.array_equal(bits(H), bits(rH)) and np.array_equal(bits(bb), bits(rb))
+    spl = O.RingIcp(100)
+    spl.prepare_plane(a, lines, origin)
+    compute.preparePointPlane(a, lines, b, origin)
+    H, bb = compute.dispatchPointPlane(b)
+    rH, rb = spl.dispatch_plane(b)
+    assert np.array_equal(bits(H), bits(rH)) and np.array_equal(bits(bb), bits(rb))
