@@ -233,6 +233,15 @@ int pcp_grid_synchronize(pcp_grid* grid);
  * (Morton-sorted, hash of occupied cells).  normals_xyzw (n rows of 4 float32, or
  * NULL) are carried along for the plane mode of pcp_grid_ls*. */
 int pcp_grid_build(pcp_grid* grid, const double* xyz, size_t n, double cell, const float* normals_xyzw);
+/* For a map split over ranks.  pcp_grid_partition cuts the Morton key space of partition cells (edge
+ * own_cell) into `world` contiguous ranges with about equal numbers of map points: cuts receives
+ * world + 1 keys, cuts[0] = 0, cuts[world] = 2^63, rank r owns [cuts[r], cuts[r+1]).
+ * pcp_grid_build_slab is pcp_grid_build for the points whose partition cell, or any of the 26 cells
+ * around it, has its key in [lo, hi) (one-cell halo), selected on the device; neighbour indices keep
+ * referring to the whole array; n_kept = points held. */
+int pcp_grid_partition(int device, const double* xyz, size_t n, double own_cell, int world, unsigned long long* cuts);
+int pcp_grid_build_slab(pcp_grid* grid, const double* xyz, size_t n, double cell, const float* normals_xyzw,
+                        double own_cell, unsigned long long lo, unsigned long long hi, size_t* n_kept);
 /* Facts about the last build: points, occupied cells, extent in cells, radix
  * passes, device time of the whole build and of the sort alone (ms). Any pointer may be NULL. */
 int pcp_grid_info(pcp_grid* grid, unsigned long long* n_points, unsigned long long* n_cells, int* extent3,

@@ -31,14 +31,17 @@ def auto_cell(points):
 
 
 class CellGrid:
-    def __init__(self, np_points, cell=None, normals=None, device=0):
+    def __init__(self, np_points, cell=None, normals=None, device=0, slab=None):
         self._lib = _lib.load()
         self._g = C.c_void_p()
         check(self._lib.pcp_grid_create(int(device), C.byref(self._g)))
         self.device = int(device)
-        self.rebuild(np_points, cell, normals)
+        self.rebuild(np_points, cell, normals, slab)
 
-    def rebuild(self, np_points, cell=None, normals=None):
+    def rebuild(self, np_points, cell=None, normals=None, slab=None):
+        """slab = (own_cell, lo, hi): keep only the points whose partition cell (edge own_cell) or one of
+        its 26 neighbours has its key in [lo, hi) -- the share of a map split over ranks, selected on the
+        device; query results keep indexing np_points."""
         pts = np.ascontiguousarray(np.asarray(np_points, dtype=np.float64)[:, :3])
         self.data = pts                                   # scipy's KDTree.data
         self.n = len(pts)
@@ -48,7 +51,14 @@ class CellGrid:
             nrm = np.zeros((len(pts), 4), dtype=np.float32)
             nn = np.asarray(normals, dtype=np.float32)
             nrm[:, :nn.shape[1]] = nn
-        check(self._lib.pcp_grid_build(self._g, f64p(pts), len(pts), self.cell, f32p(nrm)))
+        if slab is None:
+            check(self._lib.pcp_grid_build(self._g, f64p(pts), len(pts), self.cell, f32p(nrm)))
+            self.held = len(pts)
+        else:
+            kept = C.c_size_t(0)
+            check(self._lib.pcp_grid_build_slab(self._g, f64p(pts), len(pts), self.cell, f32p(nrm), float(slab[0]),
+                                                int(slab[1]), int(slab[2]), C.byref(kept)))
+            self.held = int(kept.value)
         self.m = 0
 
     def info(self):
@@ -61,8 +71,8 @@ class CellGrid:
                 "sort_passes": passes.value, "build_ms": bms.value, "sort_ms": sms.value}
 
     def sorted_points(self):
-        ids = np.zeros(self.n, dtype=np.int64)
-        xyz = np.zeros((self.n, 3), dtype=np.float64)
+        ids = np.zeros(self.held, dtype=np.int64)
+        xyz = np.zeros((self.held, 3), dtype=np.float64)
         check(self._lib.pcp_grid_sorted_ids(self._g, _i64p(ids), f64p(xyz)))
         return ids, xyz
 
@@ -149,6 +159,16 @@ class CellGrid:
             self.cleanup()
         except Exception:
             pass
+
+
+def partition_keys(points, own_cell, world, device=0):
+    """[(lo, hi)] per rank: the Morton key space of partition cells cut into `world` contiguous ranges
+    with about equal numbers of points (sorted on the device)."""
+    p = np.ascontiguousarray(np.asarray(points, dtype=np.float64)[:, :3])
+    cuts = np.zeros(int(world) + 1, dtype=np.uint64)
+    check(_lib.load().pcp_grid_partition(int(device), f64p(p), len(p), float(own_cell), int(world),
+                                         cuts.ctypes.data_as(C.POINTER(C.c_ulonglong))))
+    return [(int(cuts[r]), int(cuts[r + 1])) for r in range(int(world))]
 
 
 def cell_keys(points, cell):

@@ -34,6 +34,7 @@
 #include "pcp_ctx.h"
 #include "pcp_device.h"
 #include "pcp_host.h"
+#include "pcp_compact.h"
 #include "pcp_solve.h"
 #include "pcp_sort.h"
 
@@ -176,14 +177,14 @@ __global__ void k_close_cells(const unsigned long long* __restrict__ keys, size_
 }
 
 __global__ void k_gather_points(const double* __restrict__ xyz, const unsigned* __restrict__ vals, size_t n,
-                                const float4* __restrict__ normals_in, GridPoint* __restrict__ pts,
-                                float4* __restrict__ normals) {
+                                const float4* __restrict__ normals_in, const unsigned* __restrict__ orig,
+                                GridPoint* __restrict__ pts, float4* __restrict__ normals) {
     const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n) return;
     const unsigned i = vals[j];
     GridPoint p;
     p.x = xyz[3 * (size_t)i + 0]; p.y = xyz[3 * (size_t)i + 1]; p.z = xyz[3 * (size_t)i + 2];
-    p.id = (long long)i;
+    p.id = orig ? (long long)orig[i] : (long long)i;     // index in the caller's array
     pts[j] = p;
     if (normals_in) normals[j] = normals_in[i];
 }
@@ -587,6 +588,62 @@ __global__ void k_map_state(IcpState* __restrict__ st, int reset) {
     st->pending = 0;
 }
 
+
+// Map split over ranks: a point is kept by the rank owning keys [lo, hi) when its partition cell
+// (edge own_cell) or any of the 26 cells around it has its key in the range (one-cell halo).
+struct InSlab {
+    const double* xyz;
+    double own_cell;
+    unsigned long long lo, hi;
+    int* bad;
+    __device__ bool operator()(size_t i) const {
+        int c[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const double v = xyz[3 * i + a];
+            if (!(fabs(v / own_cell) < (double)(COORD_BIAS - 2))) { atomicOr(bad, 1); return false; }
+            c[a] = cell_of(v, own_cell) + COORD_BIAS;
+        }
+        for (int dz = -1; dz <= 1; ++dz)
+            for (int dy = -1; dy <= 1; ++dy)
+                for (int dx = -1; dx <= 1; ++dx) {
+                    const unsigned long long k = morton3((unsigned)(c[0] + dx), (unsigned)(c[1] + dy), (unsigned)(c[2] + dz));
+                    if (k >= lo && k < hi) return true;
+                }
+        return false;
+    }
+};
+
+struct EmitKept {
+    const double* xyz;
+    const float4* nrm;
+    double* xyz_out;
+    float4* nrm_out;
+    unsigned* ids_out;
+    __device__ void operator()(size_t i, size_t slot) const {
+        xyz_out[3 * slot + 0] = xyz[3 * i + 0];
+        xyz_out[3 * slot + 1] = xyz[3 * i + 1];
+        xyz_out[3 * slot + 2] = xyz[3 * i + 2];
+        if (nrm) nrm_out[slot] = nrm[i];
+        ids_out[slot] = (unsigned)i;
+    }
+};
+
+__global__ void k_partition_keys(const double* __restrict__ xyz, size_t n, double own_cell,
+                                 unsigned long long* __restrict__ keys, unsigned* __restrict__ vals, int* __restrict__ bad) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    unsigned c[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const double v = xyz[3 * i + a];
+        if (!(fabs(v / own_cell) < (double)(COORD_BIAS - 2))) atomicOr(bad, 1);
+        c[a] = (unsigned)(cell_of(v, own_cell) + COORD_BIAS);
+    }
+    keys[i] = morton3(c[0], c[1], c[2]);
+    vals[i] = (unsigned)i;
+}
+
 inline unsigned blocks_for(size_t n, int threads) { return (unsigned)((n + threads - 1) / threads); }
 
 }  // namespace
@@ -781,14 +838,9 @@ int pcp_grid_synchronize(pcp_grid* g) {
     return 0;
 }
 
-int pcp_grid_build(pcp_grid* g, const double* xyz, size_t n, double cell, const float* normals_xyzw) {
-    if (!g) return pcp_fail("null grid");
-    if (!(cell > 0.0) || !std::isfinite(cell)) return pcp_fail("cell size must be positive and finite");
-    if (n >= (1ull << 31)) return pcp_fail("%zu map points exceed the 2^31 limit of one grid", n);
-    if (n && !xyz) return pcp_fail("xyz is null");
-    PCP_CHECK(hipSetDevice(g->device));
+// Builds the grid from points already on the device (d_ids: original index of every point, or null).
+static int build_device(pcp_grid* g, const double* d_xyz, const float4* d_nrm, const unsigned* d_ids, size_t n, double cell) {
     hipStream_t s = g->stream;
-    PCP_CHECK(hipStreamSynchronize(s));
     if (free_map(g)) return 1;
     g->cell = cell;
     g->have_normals = false;
@@ -797,15 +849,11 @@ int pcp_grid_build(pcp_grid* g, const double* xyz, size_t n, double cell, const 
     g->ext[0] = g->ext[1] = g->ext[2] = 0;
     g->nn_valid = false;
     if (n == 0) return 0;
-
-    double* d_xyz = nullptr;
-    float4* d_nrm = nullptr;
     unsigned long long *k0 = nullptr, *k1 = nullptr;
     unsigned *v0 = nullptr, *v1 = nullptr, *hist = nullptr, *totals = nullptr, *base = nullptr;
     const int nblk = (int)((n + RS_TILE - 1) / RS_TILE);
     auto cleanup = [&]() {
-        for (void* q : {(void*)d_xyz, (void*)d_nrm, (void*)k0, (void*)k1, (void*)v0, (void*)v1, (void*)hist,
-                        (void*)totals, (void*)base})
+        for (void* q : {(void*)k0, (void*)k1, (void*)v0, (void*)v1, (void*)hist, (void*)totals, (void*)base})
             if (q) (void)hipFree(q);
     };
 #define GRID_TRY(expr)                                                                                      \
@@ -816,12 +864,6 @@ int pcp_grid_build(pcp_grid* g, const double* xyz, size_t n, double cell, const 
             return pcp_fail("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__);     \
         }                                                                                                   \
     } while (0)
-    GRID_TRY(hipMalloc(&d_xyz, n * 24));
-    GRID_TRY(hipMemcpyAsync(d_xyz, xyz, n * 24, hipMemcpyHostToDevice, s));
-    if (normals_xyzw) {
-        GRID_TRY(hipMalloc(&d_nrm, n * 16));
-        GRID_TRY(hipMemcpyAsync(d_nrm, normals_xyzw, n * 16, hipMemcpyHostToDevice, s));
-    }
     GRID_TRY(hipEventRecord(g->ev0, s));
     // cell range
     const int init[8] = {INT_MAX, INT_MAX, INT_MAX, INT_MIN, INT_MIN, INT_MIN, 0, 0};
@@ -875,7 +917,7 @@ int pcp_grid_build(pcp_grid* g, const double* xyz, size_t n, double cell, const 
     hipLaunchKernelGGL(k_close_cells, dim3(blocks_for(n, 256)), dim3(256), 0, s, kin, n, g->table, log_cap);
     GRID_TRY(hipMalloc(&g->pts, n * sizeof(GridPoint)));
     if (d_nrm) GRID_TRY(hipMalloc(&g->normals, n * 16));
-    hipLaunchKernelGGL(k_gather_points, dim3(blocks_for(n, 256)), dim3(256), 0, s, d_xyz, vin, n, d_nrm, g->pts, g->normals);
+    hipLaunchKernelGGL(k_gather_points, dim3(blocks_for(n, 256)), dim3(256), 0, s, d_xyz, vin, n, d_nrm, d_ids, g->pts, g->normals);
     GRID_TRY(hipEventRecord(g->ev3, s));
     GRID_TRY(hipGetLastError());
     GRID_TRY(hipStreamSynchronize(s));
@@ -885,7 +927,136 @@ int pcp_grid_build(pcp_grid* g, const double* xyz, size_t n, double cell, const 
     cleanup();
     g->n = n;
     g->cap = n;
-    g->have_normals = normals_xyzw != nullptr;
+    g->have_normals = d_nrm != nullptr;
+    return 0;
+}
+
+static int check_build_args(pcp_grid* g, const double* xyz, size_t n, double cell) {
+    if (!g) return pcp_fail("null grid");
+    if (!(cell > 0.0) || !std::isfinite(cell)) return pcp_fail("cell size must be positive and finite");
+    if (n >= (1ull << 31)) return pcp_fail("%zu map points exceed the 2^31 limit of one grid", n);
+    if (n && !xyz) return pcp_fail("xyz is null");
+    return 0;
+}
+
+int pcp_grid_build(pcp_grid* g, const double* xyz, size_t n, double cell, const float* normals_xyzw) {
+    if (check_build_args(g, xyz, n, cell)) return 1;
+    PCP_CHECK(hipSetDevice(g->device));
+    hipStream_t s = g->stream;
+    PCP_CHECK(hipStreamSynchronize(s));
+    double* d_xyz = nullptr;
+    float4* d_nrm = nullptr;
+    int rc = 0;
+    if (n) {
+        hipError_t e = hipMalloc(&d_xyz, n * 24);
+        if (e == hipSuccess) e = hipMemcpyAsync(d_xyz, xyz, n * 24, hipMemcpyHostToDevice, s);
+        if (e == hipSuccess && normals_xyzw) {
+            e = hipMalloc(&d_nrm, n * 16);
+            if (e == hipSuccess) e = hipMemcpyAsync(d_nrm, normals_xyzw, n * 16, hipMemcpyHostToDevice, s);
+        }
+        if (e != hipSuccess) rc = pcp_fail("uploading the map failed: %s", hipGetErrorString(e));
+    }
+    if (!rc) rc = build_device(g, d_xyz, d_nrm, nullptr, n, cell);
+    if (d_xyz) (void)hipFree(d_xyz);
+    if (d_nrm) (void)hipFree(d_nrm);
+    return rc;
+}
+
+int pcp_grid_build_slab(pcp_grid* g, const double* xyz, size_t n, double cell, const float* normals_xyzw,
+                        double own_cell, unsigned long long lo, unsigned long long hi, size_t* n_kept) {
+    if (check_build_args(g, xyz, n, cell)) return 1;
+    if (!(own_cell > 0.0)) return pcp_fail("partition cell size must be positive");
+    if (lo > hi) return pcp_fail("owned key range is empty");
+    PCP_CHECK(hipSetDevice(g->device));
+    hipStream_t s = g->stream;
+    PCP_CHECK(hipStreamSynchronize(s));
+    if (n_kept) *n_kept = 0;
+    double *d_xyz = nullptr, *d_keep = nullptr;
+    float4 *d_nrm = nullptr, *d_nkeep = nullptr;
+    unsigned *d_ids = nullptr, *d_counts = nullptr;
+    int* d_bad = nullptr;
+    int rc = 0;
+    auto cleanup = [&]() {
+        for (void* q : {(void*)d_xyz, (void*)d_keep, (void*)d_nrm, (void*)d_nkeep, (void*)d_ids, (void*)d_counts, (void*)d_bad})
+            if (q) (void)hipFree(q);
+    };
+    if (n == 0) return build_device(g, nullptr, nullptr, nullptr, 0, cell);
+    hipError_t e = hipMalloc(&d_xyz, n * 24);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_xyz, xyz, n * 24, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMalloc(&d_keep, n * 24);
+    if (e == hipSuccess) e = hipMalloc(&d_ids, n * 4);
+    if (e == hipSuccess) e = hipMalloc(&d_counts, compact_count_elems(n) * 4);
+    if (e == hipSuccess) e = hipMalloc(&d_bad, 4);
+    if (e == hipSuccess) e = hipMemsetAsync(d_bad, 0, 4, s);
+    if (e == hipSuccess && normals_xyzw) {
+        e = hipMalloc(&d_nrm, n * 16);
+        if (e == hipSuccess) e = hipMemcpyAsync(d_nrm, normals_xyzw, n * 16, hipMemcpyHostToDevice, s);
+        if (e == hipSuccess) e = hipMalloc(&d_nkeep, n * 16);
+    }
+    unsigned kept = 0;
+    int bad = 0;
+    if (e == hipSuccess) {
+        compact_ordered(s, InSlab{d_xyz, own_cell, lo, hi, d_bad}, EmitKept{d_xyz, d_nrm, d_keep, d_nkeep, d_ids}, n, d_counts);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(&kept, d_counts + compact_tiles(n), 4, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) rc = pcp_fail("selecting the slab failed: %s", hipGetErrorString(e));
+    else if (bad) rc = pcp_fail("map coordinates must be finite and within 2^20 partition cells of the origin");
+    if (!rc) rc = build_device(g, d_keep, d_nkeep, d_ids, (size_t)kept, cell);
+    cleanup();
+    if (!rc && n_kept) *n_kept = kept;
+    return rc;
+}
+
+int pcp_grid_partition(int device, const double* xyz, size_t n, double own_cell, int world, unsigned long long* cuts) {
+    if (!cuts || world < 1) return pcp_fail("cuts is null or world < 1");
+    if (!(own_cell > 0.0)) return pcp_fail("partition cell size must be positive");
+    if (n && !xyz) return pcp_fail("xyz is null");
+    if (n >= (1ull << 31)) return pcp_fail("%zu map points exceed the 2^31 limit", n);
+    cuts[0] = 0;
+    cuts[world] = 1ull << 63;
+    for (int r = 1; r < world; ++r) cuts[r] = 0;
+    if (world == 1 || n == 0) return 0;
+    int count = 0;
+    PCP_CHECK(hipGetDeviceCount(&count));
+    if (device < 0 || device >= count) return pcp_fail("device %d out of range (%d devices)", device, count);
+    PCP_CHECK(hipSetDevice(device));
+    double* d_xyz = nullptr;
+    unsigned long long *k0 = nullptr, *k1 = nullptr, *keys = nullptr;
+    unsigned *v0 = nullptr, *v1 = nullptr, *hist = nullptr, *totals = nullptr, *base = nullptr, *vals = nullptr;
+    int* d_bad = nullptr;
+    auto cleanup = [&]() {
+        for (void* q : {(void*)d_xyz, (void*)k0, (void*)k1, (void*)v0, (void*)v1, (void*)hist, (void*)totals, (void*)base, (void*)d_bad})
+            if (q) (void)hipFree(q);
+    };
+    hipError_t e = hipMalloc(&d_xyz, n * 24);
+    if (e == hipSuccess) e = hipMemcpy(d_xyz, xyz, n * 24, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMalloc(&k0, n * 8);
+    if (e == hipSuccess) e = hipMalloc(&k1, n * 8);
+    if (e == hipSuccess) e = hipMalloc(&v0, n * 4);
+    if (e == hipSuccess) e = hipMalloc(&v1, n * 4);
+    if (e == hipSuccess) e = hipMalloc(&hist, radix_hist_elems(n) * 4);
+    if (e == hipSuccess) e = hipMalloc(&totals, 256 * 4);
+    if (e == hipSuccess) e = hipMalloc(&base, 256 * 4);
+    if (e == hipSuccess) e = hipMalloc(&d_bad, 4);
+    if (e == hipSuccess) e = hipMemset(d_bad, 0, 4);
+    int bad = 0;
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_partition_keys, dim3(blocks_for(n, 256)), dim3(256), 0, 0, d_xyz, n, own_cell, k0, v0, d_bad);
+        radix_sort_pairs(0, k0, k1, v0, v1, n, 63, hist, totals, base, &keys, &vals);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpy(&bad, d_bad, 4, hipMemcpyDeviceToHost);
+    for (int r = 1; r < world && e == hipSuccess; ++r) {
+        const size_t at = std::min(n - 1, (n * (size_t)r) / (size_t)world);
+        e = hipMemcpy(&cuts[r], keys + at, 8, hipMemcpyDeviceToHost);
+    }
+    cleanup();
+    if (e != hipSuccess) return pcp_fail("partitioning failed: %s", hipGetErrorString(e));
+    if (bad) return pcp_fail("map coordinates must be finite and within 2^20 partition cells of the origin");
+    for (int r = 1; r <= world; ++r) cuts[r] = std::max(cuts[r], cuts[r - 1]);
     return 0;
 }
 

@@ -88,14 +88,21 @@ class HipMapBackend:
         self.tile = None
         self.stream = None
 
-    def build(self, points, normals, cell, nn_cell=None):
+    def partition(self, points, cell, world):
+        from .cell_grid import partition_keys
+        return partition_keys(points, cell, world, self.device)
+
+    def build(self, points, normals, cell, nn_cell=None, slab=None):
+        """slab = (lo, hi): build from the whole map, keeping this rank's share (selected on the device)."""
         torch = self._torch
         self.own_cell = float(cell)
         nn_cell = float(nn_cell) if nn_cell else self.own_cell
+        slab3 = None if slab is None else (self.own_cell, slab[0], slab[1])
         if self.grid is None:
-            self.grid = self._CellGrid(points, cell=nn_cell, normals=normals, device=self.device)
+            self.grid = self._CellGrid(points, cell=nn_cell, normals=normals, device=self.device, slab=slab3)
         else:
-            self.grid.rebuild(points, cell=nn_cell, normals=normals)
+            self.grid.rebuild(points, cell=nn_cell, normals=normals, slab=slab3)
+        self.held = self.grid.held
         dev = torch.device("cuda", self.device)
         self.tile = torch.zeros(64, dtype=torch.float32, device=dev)
         # kernels and collective are ordered by one stream: a torch side stream that the grid adopts
@@ -163,18 +170,24 @@ class MapRegistration:
         self.rank, self.world, self.cell = int(rank), int(world), float(cell)
         self.group = group
         self.backend = backend if backend is not None else HipMapBackend(device)
-        self.ranges = split_key_space(map_points, cell, self.world)
-        lo, hi = self.ranges[self.rank]
         pts = np.asarray(map_points, dtype=np.float64)[:, :3]
-        if self.world > 1:
-            keep = slab_mask(pts, cell, lo, hi)
-            pts = pts[keep]
-            normals = None if normals is None else np.asarray(normals)[keep]
-        self.slab_points = len(pts)
-        if nn_cell is None:
-            self.backend.build(pts, normals, self.cell)
+        on_device = hasattr(self.backend, "partition")
+        # the NumPy statement of the partition rule serves backends without a device (the CPU tests)
+        self.ranges = self.backend.partition(pts, cell, self.world) if on_device else split_key_space(pts, cell, self.world)
+        lo, hi = self.ranges[self.rank]
+        if self.world > 1 and on_device:
+            self.backend.build(pts, normals, self.cell, nn_cell, slab=(lo, hi))
+            self.slab_points = self.backend.held
         else:
-            self.backend.build(pts, normals, self.cell, nn_cell)
+            if self.world > 1:
+                keep = slab_mask(pts, cell, lo, hi)
+                pts = pts[keep]
+                normals = None if normals is None else np.asarray(normals)[keep]
+            self.slab_points = len(pts)
+            if nn_cell is None:
+                self.backend.build(pts, normals, self.cell)
+            else:
+                self.backend.build(pts, normals, self.cell, nn_cell)
         self.backend.set_owned(lo, hi)
 
     def _all_reduce(self, tile):

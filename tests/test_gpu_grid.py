@@ -355,3 +355,30 @@ def test_two_ranks_sharing_the_gpu_register_like_one(tmp_path):
             assert np.abs(r0[f"moved{mode}"] - single.moved_scan()).max() < 1e-4
     finally:
         single.close()
+
+
+def test_device_partition_and_slab_equal_the_numpy_statement():
+    from pointcloudprocessing_amd import scan_to_map as S
+    from pointcloudprocessing_amd.cell_grid import partition_keys
+    pts, nrm, src = _map_scene()
+    for world in (1, 2, 3, 5):
+        ranges = partition_keys(pts, 0.5, world)
+        assert ranges == S.split_key_space(pts, 0.5, world)
+        for lo, hi in ranges:
+            mask = S.slab_mask(pts, 0.5, lo, hi)
+            g = CellGrid(pts, cell=0.2, normals=nrm, slab=(0.5, lo, hi))
+            try:
+                ids, xyz = g.sorted_points()
+                assert g.held == mask.sum() == len(ids) and np.array_equal(np.sort(ids), np.nonzero(mask)[0])
+                assert np.array_equal(xyz, pts[ids])
+                # neighbours are reported by their index in the whole map
+                q = src[::9]
+                dist, idx = g.query(q, distance_upper_bound=0.5)
+                ref_d, ref_i = NG.exact_nn_lowest(pts[mask], q, 0.5)
+                hit = np.isfinite(ref_d)
+                assert np.array_equal(np.isfinite(dist), hit)
+                assert np.array_equal(idx[hit], np.nonzero(mask)[0][ref_i[hit]]) and np.array_equal(dist[hit], ref_d[hit])
+            finally:
+                g.cleanup()
+    with pytest.raises(RuntimeError):
+        partition_keys(np.array([[0.0, 0, 0], [1e9, 0, 0]]), 0.5, 2)
