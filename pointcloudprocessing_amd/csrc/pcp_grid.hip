@@ -22,6 +22,7 @@
 #include <hip/hip_runtime.h>
 #include <limits.h>
 #include <math.h>
+#include <stdlib.h>
 #include <stdint.h>
 #include <string.h>
 
@@ -330,6 +331,117 @@ k_grid_nn(const GridView G, const double* __restrict__ src, size_t m, double max
     nn_pos[i] = bpos;
 }
 
+
+// ------------------------------------------------------------------------------------------
+// The search with 32 lanes per query.  One lane per query leaves a scan of ~10^5 queries with a few
+// waves per SIMD, each walking a chain of dependent look-ups; here the cells of a shell are dealt out
+// to the 32 lanes of a half-wave, every lane keeps its own best, and a butterfly merges them (lowest
+// index on ties) before the shell's termination test.  Same result, 32 times the waves.
+// ------------------------------------------------------------------------------------------
+
+__device__ __forceinline__ void visit_cell_plain(const GridView& G, const int x, const int y, const int z,
+                                                 const double qx, const double qy, const double qz,
+                                                 double& best, long long& bid, int& bpos) {
+    const double gx = axis_gap(qx, (double)(x + G.cminx) * G.cell, (double)(x + G.cminx + 1) * G.cell, G.eps);
+    const double gy = axis_gap(qy, (double)(y + G.cminy) * G.cell, (double)(y + G.cminy + 1) * G.cell, G.eps);
+    const double gz = axis_gap(qz, (double)(z + G.cminz) * G.cell, (double)(z + G.cminz + 1) * G.cell, G.eps);
+    if ((gx * gx + gy * gy) + gz * gz > best) return;
+    unsigned start, count;
+    if (!find_cell(G.table, G.log_cap, morton3((unsigned)x, (unsigned)y, (unsigned)z), start, count)) return;
+    for (unsigned j = start; j < start + count; ++j) take_point(G.pts[j], j, qx, qy, qz, best, bid, bpos);
+}
+
+struct Nn32Args {
+    GridView G;
+    double* src;               // m x 3
+    size_t m;
+    double max_d2;
+    IcpState* st;              // non-null: registration loop (apply the pending step, honour done)
+    double own_cell;
+    unsigned long long own_lo, own_hi;
+    double* nn_d;
+    long long* nn_idx;
+    int* nn_pos;
+};
+
+__global__ void __launch_bounds__(256) k_grid_nn32(const Nn32Args A) {
+    const GridView& G = A.G;
+    if (A.st && A.st->done) return;
+    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t qi = gid >> 5;
+    const int sub = (int)(gid & 31);
+    const int lane = threadIdx.x & 63;
+    const int leader = lane & 32;                       // lane of the half-wave holding the query
+    const bool has = qi < A.m;
+    double qx = 0.0, qy = 0.0, qz = 0.0;
+    int owned = 0;
+    if (has && sub == 0) {
+        qx = A.src[3 * qi + 0]; qy = A.src[3 * qi + 1]; qz = A.src[3 * qi + 2];
+        if (A.st && A.st->pending) {
+            const IcpState* st = A.st;
+            const double nx = ((st->R[0] * qx + st->R[1] * qy) + st->R[2] * qz) - st->t[0];
+            const double ny = ((st->R[3] * qx + st->R[4] * qy) + st->R[5] * qz) - st->t[1];
+            const double nz = ((st->R[6] * qx + st->R[7] * qy) + st->R[8] * qz) - st->t[2];
+            qx = nx; qy = ny; qz = nz;
+            A.src[3 * qi + 0] = qx; A.src[3 * qi + 1] = qy; A.src[3 * qi + 2] = qz;
+        }
+        const unsigned long long key = morton3((unsigned)(cell_of(qx, A.own_cell) + COORD_BIAS),
+                                               (unsigned)(cell_of(qy, A.own_cell) + COORD_BIAS),
+                                               (unsigned)(cell_of(qz, A.own_cell) + COORD_BIAS));
+        owned = (key >= A.own_lo && key < A.own_hi) ? 1 : 0;
+    }
+    qx = __shfl(qx, leader, 64); qy = __shfl(qy, leader, 64); qz = __shfl(qz, leader, 64);
+    owned = __shfl(owned, leader, 64);
+    double best = A.max_d2;
+    long long bid = -1;
+    int bpos = -1;
+    const int ax = cell_of(qx, G.cell), ay = cell_of(qy, G.cell), az = cell_of(qz, G.cell);
+    const int cx = ax - G.cminx, cy = ay - G.cminy, cz = az - G.cminz;
+    auto outside = [](int c, int e) { return c < 0 ? -c : (c > e - 1 ? c - (e - 1) : 0); };
+    auto reach = [](int c, int e) { return max(c, e - 1 - c); };
+    int k = max(outside(cx, G.ex), max(outside(cy, G.ey), outside(cz, G.ez)));
+    const int k1 = max(reach(cx, G.ex), max(reach(cy, G.ey), reach(cz, G.ez)));
+    bool live = has && owned && G.n != 0 && k <= k1;     // uniform over the half-wave
+    while (live) {
+        const int z0 = max(cz - k, 0), z1 = min(cz + k, G.ez - 1);
+        const int y0 = max(cy - k, 0), y1 = min(cy + k, G.ey - 1);
+        const int x0 = max(cx - k, 0), x1 = min(cx + k, G.ex - 1);
+        const long long nx = x1 - x0 + 1, ny = y1 - y0 + 1, nz = z1 - z0 + 1;
+        const long long total = (nx > 0 && ny > 0 && nz > 0) ? nx * ny * nz : 0;
+        if (total == 1) {
+            // a shell of one cell (the query's own): its points, not the cells, are dealt out to the lanes,
+            // so the shells after it start from a tight best distance
+            unsigned start, count;
+            if (find_cell(G.table, G.log_cap, morton3((unsigned)x0, (unsigned)y0, (unsigned)z0), start, count))
+                for (unsigned j = start + sub; j < start + count; j += 32) take_point(G.pts[j], j, qx, qy, qz, best, bid, bpos);
+        } else {
+            for (long long p = sub; p < total; p += 32) {
+                const int x = x0 + (int)(p % nx), y = y0 + (int)((p / nx) % ny), z = z0 + (int)(p / (nx * ny));
+                if (max(abs(x - cx), max(abs(y - cy), abs(z - cz))) < k) continue;        // an earlier shell
+                visit_cell_plain(G, x, y, z, qx, qy, qz, best, bid, bpos);
+            }
+        }
+#pragma unroll
+        for (int sft = 16; sft > 0; sft >>= 1) {
+            const double ob = __shfl_xor(best, sft, 64);
+            const long long oi = __shfl_xor(bid, sft, 64);
+            const int op = __shfl_xor(bpos, sft, 64);
+            if (oi >= 0 && (bid < 0 || ob < best || (ob == best && oi < bid))) { best = ob; bid = oi; bpos = op; }
+        }
+        const double mx = fmin(qx - (double)(ax - k) * G.cell, (double)(ax + k + 1) * G.cell - qx);
+        const double my = fmin(qy - (double)(ay - k) * G.cell, (double)(ay + k + 1) * G.cell - qy);
+        const double mz = fmin(qz - (double)(az - k) * G.cell, (double)(az + k + 1) * G.cell - qz);
+        const double mrg = fmin(mx, fmin(my, mz)) - G.eps;
+        ++k;
+        if ((mrg > 0.0 && best < mrg * mrg) || k > k1) live = false;
+    }
+    if (has && sub == 0) {
+        A.nn_d[qi] = (bid >= 0) ? sqrt(best) : INFINITY;
+        A.nn_idx[qi] = bid;
+        A.nn_pos[qi] = bpos;
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // trimmed Kabsch step (icp_step_KD): selection of the `taken` smallest distances, sums
 // ------------------------------------------------------------------------------------------
@@ -552,6 +664,42 @@ __global__ void __launch_bounds__(PCP_BLOCK) k_map_ls(const MapLsArgs A) {
     }
 }
 
+// Second stage of a scan-to-map iteration: tile values from the neighbours k_grid_nn32 found.
+template <int MODE>
+__global__ void __launch_bounds__(PCP_BLOCK)
+k_map_tiles(const GridView G, const float4* __restrict__ normals, const double* __restrict__ src,
+            const int* __restrict__ nn_pos, const IcpState* __restrict__ st, size_t m, float* __restrict__ partials) {
+    if (st->done) return;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    float v[PCP_NVAL];
+#pragma unroll
+    for (int k = 0; k < PCP_NVAL; ++k) v[k] = 0.0f;
+    if (i < m) {
+        const int bpos = nn_pos[i];
+        if (bpos >= 0) {
+            const GridPoint p = G.pts[bpos];
+            const float4 pa = make_float4((float)p.x, (float)p.y, (float)p.z, 0.0f);
+            const float4 q = make_float4((float)src[3 * i + 0], (float)src[3 * i + 1], (float)src[3 * i + 2], 0.0f);
+            const float d = distsq(q, pa);
+            if (MODE == PCP_MODE_POINT) ls_point_values(pa, q, d, v);
+            else ls_plane_values(pa, q, normals[bpos], d, v);
+        }
+    }
+    const int lane = threadIdx.x & 63;
+    const size_t wave = i >> 6;
+    if ((wave << 6) < m) {
+#pragma unroll
+        for (int k = 0; k < PCP_NVAL; ++k) v[k] = wave_tree_sum(v[k]);
+        float mine = 0.0f;
+#pragma unroll
+        for (int k = 0; k < PCP_NVAL; ++k) {
+            const float vk = __shfl(v[k], 0, 64);
+            mine = (lane == k) ? vk : mine;
+        }
+        if (lane < PCP_PSTRIDE) partials[wave * PCP_PSTRIDE + lane] = mine;
+    }
+}
+
 __global__ void __launch_bounds__(1024)
 k_map_finish(const FinishArgs F, int solve, int mode, int max_iter, float tol, int full_iter) {
     finish_body(F, solve, mode, max_iter, tol, full_iter);
@@ -756,10 +904,49 @@ MapLsArgs map_args(pcp_grid* g, double radius, bool per_point) {
     return A;
 }
 
+// Which search kernel: with few queries a launch is a handful of waves per SIMD walking dependent
+// look-ups, and 32 lanes per query win (12 M-point map, 122 k queries: 1.7 -> 0.65 ms); with many
+// queries the GPU is full either way and one lane per query does less redundant work (1 M queries:
+// 0.26 against 0.67 ms).  PCP_GRID_LANES=1 or =32 in the environment forces one of them.
+constexpr size_t LANES32_MAX_QUERIES = 262144;
+bool lane_per_query(const size_t m) {
+    static const int forced = [] {
+        const char* e = getenv("PCP_GRID_LANES");
+        return !e ? 0 : (e[0] == '1' && e[1] == 0 ? 1 : (e[0] == '3' && e[1] == '2' && e[2] == 0 ? 32 : 0));
+    }();
+    return forced == 1 || (forced == 0 && m > LANES32_MAX_QUERIES);
+}
+
+int launch_nn32(pcp_grid* g, double max_d2, bool in_loop) {
+    Nn32Args A;
+    A.G = view_of(g);
+    A.src = g->src; A.m = g->m; A.max_d2 = max_d2;
+    A.st = in_loop ? g->state : nullptr;
+    A.own_cell = in_loop ? g->own_cell : 1.0;
+    A.own_lo = in_loop ? g->own_lo : 0ull;
+    A.own_hi = in_loop ? g->own_hi : ~0ull;
+    A.nn_d = g->nn_d; A.nn_idx = g->nn_idx; A.nn_pos = g->nn_pos;
+    hipLaunchKernelGGL(k_grid_nn32, dim3(blocks_for(g->m * 32, 256)), dim3(256), 0, g->stream, A);
+    PCP_CHECK(hipGetLastError());
+    return 0;
+}
+
 int launch_map_ls(pcp_grid* g, int mode, double radius, bool per_point) {
     if (mode != PCP_MODE_POINT && mode != PCP_MODE_PLANE) return pcp_fail("unknown mode %d", mode);
     if (mode == PCP_MODE_PLANE && !g->have_normals) return pcp_fail("plane mode needs map normals (pcp_grid_build)");
     if (!(radius > 0.0)) return pcp_fail("search radius must be positive");
+    if (!lane_per_query(g->m)) {
+        if (launch_nn32(g, radius * radius, true)) return 1;
+        const unsigned nb = blocks_for(g->m, PCP_BLOCK);
+        if (mode == PCP_MODE_POINT)
+            hipLaunchKernelGGL(k_map_tiles<PCP_MODE_POINT>, dim3(nb), dim3(PCP_BLOCK), 0, g->stream, view_of(g), g->normals,
+                               g->src, g->nn_pos, g->state, g->m, g->partials);
+        else
+            hipLaunchKernelGGL(k_map_tiles<PCP_MODE_PLANE>, dim3(nb), dim3(PCP_BLOCK), 0, g->stream, view_of(g), g->normals,
+                               g->src, g->nn_pos, g->state, g->m, g->partials);
+        PCP_CHECK(hipGetLastError());
+        return 0;
+    }
     const MapLsArgs A = map_args(g, radius, per_point);
     const unsigned blocks = blocks_for(g->m, PCP_BLOCK);
     if (mode == PCP_MODE_POINT) hipLaunchKernelGGL(k_map_ls<PCP_MODE_POINT>, dim3(blocks), dim3(PCP_BLOCK), 0, g->stream, A);
@@ -1141,9 +1328,13 @@ int pcp_grid_query_resident(pcp_grid* g, double max_dist, long long* idx, double
     PCP_CHECK(hipSetDevice(g->device));
     const double max_d2 = (max_dist > 0.0 && std::isfinite(max_dist)) ? max_dist * max_dist : INFINITY;
     PCP_CHECK(hipEventRecord(g->ev0, g->stream));
-    hipLaunchKernelGGL(k_grid_nn, dim3(blocks_for(g->m, 256)), dim3(256), 0, g->stream, view_of(g), g->src, g->m, max_d2,
-                       g->nn_d, g->nn_idx, g->nn_pos);
-    PCP_CHECK(hipGetLastError());
+    if (lane_per_query(g->m)) {
+        hipLaunchKernelGGL(k_grid_nn, dim3(blocks_for(g->m, 256)), dim3(256), 0, g->stream, view_of(g), g->src, g->m, max_d2,
+                           g->nn_d, g->nn_idx, g->nn_pos);
+        PCP_CHECK(hipGetLastError());
+    } else if (launch_nn32(g, max_d2, false)) {
+        return 1;
+    }
     PCP_CHECK(hipEventRecord(g->ev1, g->stream));
     if (idx) PCP_CHECK(hipMemcpyAsync(idx, g->nn_idx, g->m * 8, hipMemcpyDeviceToHost, g->stream));
     if (dist) PCP_CHECK(hipMemcpyAsync(dist, g->nn_d, g->m * 8, hipMemcpyDeviceToHost, g->stream));
@@ -1168,8 +1359,12 @@ int pcp_grid_kd_step(pcp_grid* g, double keep_fraction, double* mean_ref, double
     const size_t m = g->m;
     const unsigned long long taken = (unsigned long long)((double)m * keep_fraction);    // int(len * percent)
     if (taken == 0) return pcp_fail("keep_fraction selects no point");
-    hipLaunchKernelGGL(k_grid_nn, dim3(blocks_for(m, 256)), dim3(256), 0, s, view_of(g), g->src, m, (double)INFINITY,
-                       g->nn_d, g->nn_idx, g->nn_pos);
+    if (lane_per_query(m)) {
+        hipLaunchKernelGGL(k_grid_nn, dim3(blocks_for(m, 256)), dim3(256), 0, s, view_of(g), g->src, m, (double)INFINITY,
+                           g->nn_d, g->nn_idx, g->nn_pos);
+    } else if (launch_nn32(g, (double)INFINITY, false)) {
+        return 1;
+    }
     hipLaunchKernelGGL(k_sel_init, dim3(1), dim3(1), 0, s, g->sel_state, taken);
     const unsigned hb = std::min<unsigned>(blocks_for(m, 256), 1024);
     for (int shift = 56; shift >= 0; shift -= 8) {
