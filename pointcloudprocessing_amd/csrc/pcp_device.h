@@ -70,6 +70,14 @@ __device__ __forceinline__ float4 ld4(const gf4_t p, const size_t i) {
     const pcp_f4 v = p[i];
     return make_float4(v.x, v.y, v.z, v.w);
 }
+// Element i >= 0 of an array of fewer than 2^28 elements: the byte offset is formed in 32 bits, which
+// lets the load use the (uniform 64-bit base + 32-bit lane offset) addressing mode instead of a
+// 64-bit address computed per lane.
+__device__ __forceinline__ float4 ld4i(const gf4_t p, const int i) {
+    const unsigned off = (unsigned)i << 4;
+    const pcp_f4 v = *(gf4_t)((const char PCP_GLOBAL*)p + off);
+    return make_float4(v.x, v.y, v.z, v.w);
+}
 
 struct Target {
     gf4_t a;                         // target points
@@ -88,7 +96,7 @@ struct Target {
 // arithmetic with the one integer division hoisted: the absolute midpoint
 // (begin+end)/2 is reduced mod L once, every later step stays inside (-L, 2L)
 // and wraps with a compare.  exclude < 0 disables the 'test != pindex' clause.
-template <int CHECK>
+template <int CHECK, bool EXCL>
 __device__ __forceinline__ void ring_window(const Target& T, const float4 q, const float4 ref,
                                             const int beg, const int end, const int exclude,
                                             int& best, float& mind) {
@@ -99,8 +107,8 @@ __device__ __forceinline__ void ring_window(const Target& T, const float4 q, con
         // 2*CHECK window slots are the ring's single point.
         const int closest = beg + (beg + end) / 2;
         best = min(closest, T.n_a - 1);
-        const float d = distsq(q, ld4(T.a, beg));
-        if (d < mind && beg != exclude) { mind = d; best = beg; }
+        const float d = distsq(q, ld4i(T.a, beg));
+        if (d < mind && (!EXCL || beg != exclude)) { mind = d; best = beg; }
         return;
     }
     int idx = ((beg + end) / 2) % L;
@@ -109,30 +117,45 @@ __device__ __forceinline__ void ring_window(const Target& T, const float4 q, con
     for (int i = 0; i < runs; ++i) {
         const int i1 = (idx == 0) ? L - 1 : idx - 1;
         const int i2 = (idx + 1 == L) ? 0 : idx + 1;
-        const float c1 = dot4(ld4(T.ua, beg + i1), ref) + 1.0f;
-        const float c2 = dot4(ld4(T.ua, beg + i2), ref) + 1.0f;
+        const float c1 = dot4(ld4i(T.ua, beg + i1), ref) + 1.0f;
+        const float c2 = dot4(ld4i(T.ua, beg + i2), ref) + 1.0f;
         int t = (c1 > c2) ? idx - half : idx + half;
         t = (t < 0) ? t + L : ((t >= L) ? t - L : t);
         idx = t;
         half = (half + 1) >> 1;
     }
     best = beg + idx;
-    if (L >= CHECK) {
+    if (idx >= CHECK && idx + CHECK <= L) {
+        // The window does not wrap (all but the lanes within CHECK points of the ring's ends): its
+        // 2*CHECK points are consecutive, so one address serves them all and the winner is kept as
+        // a slot number.  Same slots, same order, same strict '<' as the general walk below.
+        const int first = beg + idx - CHECK;
+        const gf4_t w = (gf4_t)((const char PCP_GLOBAL*)T.a + ((unsigned)first << 4));
+        const int skip = EXCL ? exclude - first : -1;
+        int slot = -1;
+#pragma unroll
+        for (int i = 0; i < 2 * CHECK; ++i) {
+            const pcp_f4 p = w[i];
+            const float d = distsq(q, make_float4(p.x, p.y, p.z, p.w));
+            if (d < mind && (!EXCL || i != skip)) { mind = d; slot = i; }
+        }
+        if (slot >= 0) best = first + slot;
+    } else if (L >= CHECK) {
 #pragma unroll
         for (int i = -CHECK; i < CHECK; ++i) {
             int t = idx + i;
             t = (t < 0) ? t + L : ((t >= L) ? t - L : t);
             const int test = beg + t;
-            const float d = distsq(q, ld4(T.a, test));
-            if (d < mind && test != exclude) { mind = d; best = test; }
+            const float d = distsq(q, ld4i(T.a, test));
+            if (d < mind && (!EXCL || test != exclude)) { mind = d; best = test; }
         }
     } else {
         for (int i = -CHECK; i < CHECK; ++i) {
             int t = (idx + i + L) % L;
             if (t < 0) t += L;
             const int test = beg + t;
-            const float d = distsq(q, ld4(T.a, test));
-            if (d < mind && test != exclude) { mind = d; best = test; }
+            const float d = distsq(q, ld4i(T.a, test));
+            if (d < mind && (!EXCL || test != exclude)) { mind = d; best = test; }
         }
     }
 }
@@ -236,7 +259,7 @@ __device__ __forceinline__ int find_closest(const Target& T, const float4 q, flo
         const int2 se = T.scan[r];
         int best;
         float d;
-        ring_window<10>(T, q, ref, se.x, se.y, -1, best, d);
+        ring_window<10, false>(T, q, ref, se.x, se.y, -1, best, d);
         if (d < mind || (d == mind && ring >= 0 && r < ring)) { mind = d; glob = best; ring = r; }
     }
     if (ring >= 0) hint = (float)ring;

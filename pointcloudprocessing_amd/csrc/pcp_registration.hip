@@ -166,7 +166,7 @@ __device__ __forceinline__ int closest_distinct(const Target& T, const float4 q,
     const int2 se = T.scan[ring];
     int best;
     float d;
-    ring_window<CHECK>(T, q, ref, se.x, se.y, pid, best, d);
+    ring_window<CHECK, true>(T, q, ref, se.x, se.y, pid, best, d);
     return best;
 }
 
@@ -247,7 +247,7 @@ struct LsArgs {
 };
 
 template <int MODE, bool F64SRC>
-__device__ __forceinline__ void ls_body(const LsArgs& A, char* smem) {
+__device__ __forceinline__ void ls_body(const LsArgs& A, char* smem, const unsigned block) {
     const float4* __restrict__ a = A.a;
     const float4* __restrict__ normals = A.normals;
     const double* __restrict__ b_in = A.b_in;
@@ -263,7 +263,7 @@ __device__ __forceinline__ void ls_body(const LsArgs& A, char* smem) {
     const int2* s_scan;
     const float4* s_stat;
     load_rings(smem, A.scan, A.stat, A.Z, s_scan, s_stat);
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = block * blockDim.x + threadIdx.x;
     const bool in = i < n_b;
     float v[PCP_NVAL];
 #pragma unroll
@@ -334,16 +334,36 @@ __device__ __forceinline__ void ls_body(const LsArgs& A, char* smem) {
 template <int MODE, bool F64SRC>
 __global__ void __launch_bounds__(PCP_BLOCK) k_ls(const LsArgs A) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    ls_body<MODE, F64SRC>(A, smem);
+    ls_body<MODE, F64SRC>(A, smem, blockIdx.x);
 }
 
-// The same for a batch of independent pairs: blockIdx.y selects the pair.
+// Which (pair, block) a workgroup of a batched launch works on.  Workgroups are dealt to the eight
+// XCDs round-robin by their linear index, and every XCD has an L2 of its own: with the plain
+// (blockIdx.y, blockIdx.x) reading all XCDs walk through the same pairs together and each L2 sees the
+// targets of every pair in flight.  When the number of pairs is a multiple of 8 the linear index is
+// re-read so that pair p runs on the XCD p mod 8 gets, one pair after the other: an L2 then serves one
+// or two targets at a time.  A pure renumbering: every (pair, block) is still taken exactly once.
+__device__ __forceinline__ void pair_and_block(unsigned& pair, unsigned& block) {
+    pair = blockIdx.y;
+    block = blockIdx.x;
+    if ((gridDim.y & 7u) == 0u) {
+        const unsigned lin = blockIdx.y * gridDim.x + blockIdx.x;
+        const unsigned slot = lin >> 3;
+        const unsigned local = slot / gridDim.x;
+        block = slot - local * gridDim.x;
+        pair = (lin & 7u) + 8u * local;
+    }
+}
+
+// The same for a batch of independent pairs.
 template <int MODE>
 __global__ void __launch_bounds__(PCP_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) k_ls_batch(const LsArgs* __restrict__ all) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const LsArgs A = all[blockIdx.y];
-    if ((int)(blockIdx.x * PCP_BLOCK) >= A.n_b) return;
-    ls_body<MODE, true>(A, smem);
+    unsigned pair, block;
+    pair_and_block(pair, block);
+    const LsArgs A = all[pair];
+    if ((int)(block * PCP_BLOCK) >= A.n_b) return;
+    ls_body<MODE, true>(A, smem, block);
 }
 
 
