@@ -52,6 +52,9 @@ __device__ __forceinline__ float4 unit_sphere(const float4 p, const float4 o) {
     return make_float4(v.x / len, v.y / len, v.z / len, v.w / len);
 }
 
+#ifndef PCP_WIN_GROUP
+#define PCP_WIN_GROUP 7           // window loads in flight per lane
+#endif
 #define PCP_AZ_BINS 64            // azimuth bins of the per-ring elevation table
 // 0.999 * (sin(0.99 * 2 pi / PCP_AZ_BINS) - 1e-5)^2, rounded down: squared sine of the smallest
 // azimuth gap between a query and a target point two or more bins away, with the margins of
@@ -115,13 +118,23 @@ __device__ __forceinline__ void ring_window(const Target& T, const float4 q, con
     int half = L / 2;
     const int runs = 32 - __clz(L - 1);           // exact ceil(log2(L)), L >= 2
     for (int i = 0; i < runs; ++i) {
-        const int i1 = (idx == 0) ? L - 1 : idx - 1;
-        const int i2 = (idx + 1 == L) ? 0 : idx + 1;
-        const float c1 = dot4(ld4i(T.ua, beg + i1), ref) + 1.0f;
-        const float c2 = dot4(ld4i(T.ua, beg + i2), ref) + 1.0f;
-        int t = (c1 > c2) ? idx - half : idx + half;
-        t = (t < 0) ? t + L : ((t >= L) ? t - L : t);
-        idx = t;
+        float c1, c2;
+        if (__any(idx == 0 || idx + 1 == L)) {        // some lane of the wave is at an end of its ring
+            const int i1 = (idx == 0) ? L - 1 : idx - 1;
+            const int i2 = (idx + 1 == L) ? 0 : idx + 1;
+            c1 = dot4(ld4i(T.ua, beg + i1), ref) + 1.0f;
+            c2 = dot4(ld4i(T.ua, beg + i2), ref) + 1.0f;
+        } else {                                      // both neighbours sit beside idx: one address
+            const gf4_t m = (gf4_t)((const char PCP_GLOBAL*)T.ua + ((unsigned)(beg + idx) << 4));
+            const pcp_f4 v1 = m[-1], v2 = m[1];
+            c1 = dot4(make_float4(v1.x, v1.y, v1.z, v1.w), ref) + 1.0f;
+            asm volatile("" : "+v"(c1));              // keeps the two sums from being interleaved lane-pairwise
+            c2 = dot4(make_float4(v2.x, v2.y, v2.z, v2.w), ref) + 1.0f;
+        }
+        // idx -+ half lies in (-L, 2L): of t, t + L and t - L exactly one is in [0, L), and read as
+        // unsigned numbers it is the smallest of the three
+        const unsigned t = (unsigned)((c1 > c2) ? idx - half : idx + half);
+        idx = (int)min(min(t, t + (unsigned)L), t - (unsigned)L);
         half = (half + 1) >> 1;
     }
     best = beg + idx;
@@ -133,11 +146,25 @@ __device__ __forceinline__ void ring_window(const Target& T, const float4 q, con
         const gf4_t w = (gf4_t)((const char PCP_GLOBAL*)T.a + ((unsigned)first << 4));
         const int skip = EXCL ? exclude - first : -1;
         int slot = -1;
+        // PCP_WIN_GROUP loads are issued together before their distances are evaluated: the window
+        // then costs ceil(2*CHECK / PCP_WIN_GROUP) memory round trips of the wave instead of one per
+        // few slots, within the register budget of 8 resident waves per SIMD.
 #pragma unroll
-        for (int i = 0; i < 2 * CHECK; ++i) {
-            const pcp_f4 p = w[i];
-            const float d = distsq(q, make_float4(p.x, p.y, p.z, p.w));
-            if (d < mind && (!EXCL || i != skip)) { mind = d; slot = i; }
+        for (int g = 0; g < 2 * CHECK; g += PCP_WIN_GROUP) {
+            pcp_f4 p[PCP_WIN_GROUP];
+#pragma unroll
+            for (int i = 0; i < PCP_WIN_GROUP; ++i)
+                if (g + i < 2 * CHECK) p[i] = w[g + i];
+#pragma unroll
+            for (int i = 0; i < PCP_WIN_GROUP; ++i)
+                if (g + i < 2 * CHECK) asm volatile("" : "+v"(p[i]));      // all of the group's loads precede its arithmetic
+#pragma unroll
+            for (int i = 0; i < PCP_WIN_GROUP; ++i) {
+                if (g + i < 2 * CHECK) {
+                    const float d = distsq(q, make_float4(p[i].x, p[i].y, p[i].z, p[i].w));
+                    if (d < mind && (!EXCL || g + i != skip)) { mind = d; slot = g + i; }
+                }
+            }
         }
         if (slot >= 0) best = first + slot;
     } else if (L >= CHECK) {

@@ -356,8 +356,11 @@ __device__ __forceinline__ void pair_and_block(unsigned& pair, unsigned& block) 
 }
 
 // The same for a batch of independent pairs.
+#ifndef PCP_LS_WAVES
+#define PCP_LS_WAVES 8      // resident waves per SIMD the register budget is set for
+#endif
 template <int MODE>
-__global__ void __launch_bounds__(PCP_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) k_ls_batch(const LsArgs* __restrict__ all) {
+__global__ void __launch_bounds__(PCP_BLOCK) __attribute__((amdgpu_waves_per_eu(PCP_LS_WAVES, PCP_LS_WAVES))) k_ls_batch(const LsArgs* __restrict__ all) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     unsigned pair, block;
     pair_and_block(pair, block);
