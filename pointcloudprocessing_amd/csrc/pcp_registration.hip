@@ -159,6 +159,24 @@ k_nn(const float4* __restrict__ a, const float4* __restrict__ ua, const int2* __
     dist[i] = distsq(q, a[nn]);
 }
 
+// Which (pair, block) a workgroup of a batched launch works on.  Workgroups are dealt to the eight
+// XCDs round-robin by their linear index, and every XCD has an L2 of its own: with the plain
+// (blockIdx.y, blockIdx.x) reading all XCDs walk through the same pairs together and each L2 sees the
+// targets of every pair in flight.  When the number of pairs is a multiple of 8 the linear index is
+// re-read so that pair p runs on the XCD p mod 8 gets, one pair after the other: an L2 then serves one
+// or two targets at a time.  A pure renumbering: every (pair, block) is still taken exactly once.
+__device__ __forceinline__ void pair_and_block(unsigned& pair, unsigned& block) {
+    pair = blockIdx.y;
+    block = blockIdx.x;
+    if ((gridDim.y & 7u) == 0u) {
+        const unsigned lin = blockIdx.y * gridDim.x + blockIdx.x;
+        const unsigned slot = lin >> 3;
+        const unsigned local = slot / gridDim.x;
+        block = slot - local * gridDim.x;
+        pair = (lin & 7u) + 8u * local;
+    }
+}
+
 // NormalShader.glsl:73-101
 template <int CHECK>
 __device__ __forceinline__ int closest_distinct(const Target& T, const float4 q, const float4 ref,
@@ -172,11 +190,12 @@ __device__ __forceinline__ int closest_distinct(const Target& T, const float4 q,
 
 __device__ __forceinline__ void normals_body(const float4* __restrict__ a, const float4* __restrict__ ua,
                                              const int2* __restrict__ scan, const float4* __restrict__ stat,
-                                             int n_a, int Z, float4 o, float4* __restrict__ normals, char* smem) {
+                                             int n_a, int Z, float4 o, float4* __restrict__ normals, char* smem,
+                                             const unsigned block) {
     const int2* s_scan;
     const float4* s_stat;
     load_rings(smem, scan, stat, Z, s_scan, s_stat);
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = block * blockDim.x + threadIdx.x;
     if (i >= n_a) return;
     const Target T{as_global(a), as_global(ua), s_scan, s_stat, nullptr, n_a, Z, o};
     // getScanLineOfPoint, NormalShader.glsl:1-10: first ring that contains the point
@@ -222,14 +241,16 @@ __global__ void __launch_bounds__(PCP_BLOCK)
 k_normals(const float4* __restrict__ a, const float4* __restrict__ ua, const int2* __restrict__ scan,
           const float4* __restrict__ stat, int n_a, int Z, float4 o, float4* __restrict__ normals) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    normals_body(a, ua, scan, stat, n_a, Z, o, normals, smem);
+    normals_body(a, ua, scan, stat, n_a, Z, o, normals, smem, blockIdx.x);
 }
 
 __global__ void __launch_bounds__(PCP_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) k_normals_batch(const PrepArgs* __restrict__ all) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const PrepArgs P = all[blockIdx.y];
-    if ((int)(blockIdx.x * PCP_BLOCK) >= P.n_a) return;
-    normals_body(P.a, P.ua, P.scan, P.stat, P.n_a, P.Z, P.o, P.normals, smem);
+    unsigned pair, block;
+    pair_and_block(pair, block);
+    const PrepArgs P = all[pair];
+    if ((int)(block * PCP_BLOCK) >= P.n_a) return;
+    normals_body(P.a, P.ua, P.scan, P.stat, P.n_a, P.Z, P.o, P.normals, smem, block);
 }
 
 // LeastSquaresPoint.glsl / LeastSquaresPlane.glsl fused with the first level of
@@ -335,24 +356,6 @@ template <int MODE, bool F64SRC>
 __global__ void __launch_bounds__(PCP_BLOCK) k_ls(const LsArgs A) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     ls_body<MODE, F64SRC>(A, smem, blockIdx.x);
-}
-
-// Which (pair, block) a workgroup of a batched launch works on.  Workgroups are dealt to the eight
-// XCDs round-robin by their linear index, and every XCD has an L2 of its own: with the plain
-// (blockIdx.y, blockIdx.x) reading all XCDs walk through the same pairs together and each L2 sees the
-// targets of every pair in flight.  When the number of pairs is a multiple of 8 the linear index is
-// re-read so that pair p runs on the XCD p mod 8 gets, one pair after the other: an L2 then serves one
-// or two targets at a time.  A pure renumbering: every (pair, block) is still taken exactly once.
-__device__ __forceinline__ void pair_and_block(unsigned& pair, unsigned& block) {
-    pair = blockIdx.y;
-    block = blockIdx.x;
-    if ((gridDim.y & 7u) == 0u) {
-        const unsigned lin = blockIdx.y * gridDim.x + blockIdx.x;
-        const unsigned slot = lin >> 3;
-        const unsigned local = slot / gridDim.x;
-        block = slot - local * gridDim.x;
-        pair = (lin & 7u) + 8u * local;
-    }
 }
 
 // The same for a batch of independent pairs.
