@@ -78,6 +78,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--pairs", type=int, default=16, help="independent frame pairs per GPU per step")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="the pairs of a step are split into this many batches, each on a stream of its own")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -100,7 +102,8 @@ def main():
     local_rank = device
 
     def barrier():
-        batch.synchronize()
+        for bt in batches:
+            bt.synchronize()
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
@@ -113,11 +116,14 @@ def main():
         b, R, t = moved_copy(a, 1000 * rank + p)
         pairs.append(Pair(local_rank, a, lines, b))
         truth.append((R, t))
-    batch = IcpBatch([p.cs for p in pairs])
+    per = -(-args.pairs // max(1, args.streams))
+    batches = [IcpBatch([p.cs for p in pairs[lo:lo + per]]) for lo in range(0, args.pairs, per)]
 
     def step():
-        batch.prepare(True)                                   # unit vectors, ring bands, hints, normals
-        batch.launch(MODE_PLANE, MAX_ITER, TOL, False)        # the whole iteration loop of every pair
+        for bt in batches:
+            bt.prepare(True)                                  # unit vectors, ring bands, hints, normals
+        for bt in batches:
+            bt.launch(MODE_PLANE, MAX_ITER, TOL, False)       # the whole iteration loop of every pair
 
     for _ in range(args.warmup):
         step()
@@ -151,15 +157,18 @@ def main():
 
     # roofline leg: the same steps again with a HIP event before/after every fused
     # NN + least-squares launch, on the stream those launches run on
-    batch.profile(True)
+    for bt in batches:
+        bt.profile(True)
     ls_ms, ls_launches, ls_points = 0.0, 0, 0
     for _ in range(max(1, min(args.steps, 5))):
         step()
-        ms, n, pts = batch.profile_read()
-        ls_ms += ms
-        ls_launches += n
-        ls_points += pts
-    batch.profile(False)
+        for bt in batches:
+            ms, n, pts = bt.profile_read()
+            ls_ms += ms
+            ls_launches += n
+            ls_points += pts
+    for bt in batches:
+        bt.profile(False)
     avg_iters = float(np.mean(iters))
     # algorithmic bytes of one launch = 32 B per source point it processed + the 32 B per target
     # point (point + normal) each pair reads once, spread over that pair's launches
@@ -216,7 +225,8 @@ def main():
             "cpu_baseline": cpu,
         }
         print(json.dumps(out))
-    batch.close()
+    for bt in batches:
+        bt.close()
     for p in pairs:
         p.cs.cleanup()
     if dist is not None:
