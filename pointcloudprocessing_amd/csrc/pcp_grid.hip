@@ -339,18 +339,6 @@ k_grid_nn(const GridView G, const double* __restrict__ src, size_t m, double max
 // index on ties) before the shell's termination test.  Same result, 32 times the waves.
 // ------------------------------------------------------------------------------------------
 
-__device__ __forceinline__ void visit_cell_plain(const GridView& G, const int x, const int y, const int z,
-                                                 const double qx, const double qy, const double qz,
-                                                 double& best, long long& bid, int& bpos) {
-    const double gx = axis_gap(qx, (double)(x + G.cminx) * G.cell, (double)(x + G.cminx + 1) * G.cell, G.eps);
-    const double gy = axis_gap(qy, (double)(y + G.cminy) * G.cell, (double)(y + G.cminy + 1) * G.cell, G.eps);
-    const double gz = axis_gap(qz, (double)(z + G.cminz) * G.cell, (double)(z + G.cminz + 1) * G.cell, G.eps);
-    if ((gx * gx + gy * gy) + gz * gz > best) return;
-    unsigned start, count;
-    if (!find_cell(G.table, G.log_cap, morton3((unsigned)x, (unsigned)y, (unsigned)z), start, count)) return;
-    for (unsigned j = start; j < start + count; ++j) take_point(G.pts[j], j, qx, qy, qz, best, bid, bpos);
-}
-
 struct Nn32Args {
     GridView G;
     double* src;               // m x 3
@@ -366,6 +354,7 @@ struct Nn32Args {
 
 __global__ void __launch_bounds__(256) k_grid_nn32(const Nn32Args A) {
     const GridView& G = A.G;
+    __shared__ uint2 s_seg[8][32];          // per half-wave: (first point, offset in the dealt list) of 32 cells
     if (A.st && A.st->done) return;
     const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t qi = gid >> 5;
@@ -415,10 +404,49 @@ __global__ void __launch_bounds__(256) k_grid_nn32(const Nn32Args A) {
             if (find_cell(G.table, G.log_cap, morton3((unsigned)x0, (unsigned)y0, (unsigned)z0), start, count))
                 for (unsigned j = start + sub; j < start + count; j += 32) take_point(G.pts[j], j, qx, qy, qz, best, bid, bpos);
         } else {
-            for (long long p = sub; p < total; p += 32) {
-                const int x = x0 + (int)(p % nx), y = y0 + (int)((p / nx) % ny), z = z0 + (int)(p / (nx * ny));
-                if (max(abs(x - cx), max(abs(y - cy), abs(z - cz))) < k) continue;        // an earlier shell
-                visit_cell_plain(G, x, y, z, qx, qy, qz, best, bid, bpos);
+            // 32 cells at a time: every lane looks ONE cell up, then the points of the cells found are
+            // dealt out evenly over the 32 lanes (an exclusive scan of the counts and a search of that
+            // scan in LDS tell a lane which cell its e-th point belongs to).  A lane walking its own
+            // cell's points one after the other would make the fullest cell set the half-wave's time.
+            for (long long p0 = 0; p0 < total; p0 += 32) {                  // uniform over the half-wave
+                const long long p = p0 + sub;
+                unsigned start = 0, count = 0;
+                if (p < total) {
+                    const int x = x0 + (int)(p % nx), y = y0 + (int)((p / nx) % ny), z = z0 + (int)(p / (nx * ny));
+                    if (max(abs(x - cx), max(abs(y - cy), abs(z - cz))) >= k) {      // not an earlier shell
+                        const double gx = axis_gap(qx, (double)(x + G.cminx) * G.cell, (double)(x + G.cminx + 1) * G.cell, G.eps);
+                        const double gy = axis_gap(qy, (double)(y + G.cminy) * G.cell, (double)(y + G.cminy + 1) * G.cell, G.eps);
+                        const double gz = axis_gap(qz, (double)(z + G.cminz) * G.cell, (double)(z + G.cminz + 1) * G.cell, G.eps);
+                        if (!((gx * gx + gy * gy) + gz * gz > best))
+                            if (!find_cell(G.table, G.log_cap, morton3((unsigned)x, (unsigned)y, (unsigned)z), start, count)) count = 0;
+                    }
+                }
+                unsigned inc = count;
+#pragma unroll
+                for (int d = 1; d < 32; d <<= 1) {
+                    const unsigned o = __shfl_up(inc, d, 32);
+                    if (sub >= d) inc += o;
+                }
+                const unsigned tot = __shfl(inc, 31, 32);
+                if (tot == 0) continue;
+                uint2* const seg = s_seg[threadIdx.x >> 5];
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // the previous round's reads are done
+                seg[sub] = make_uint2(start, inc - count);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                for (unsigned e = sub; e < tot; e += 32) {
+                    int lo = 0, hi = 31;                                     // last cell whose offset is <= e
+                    uint2 sg = seg[0];
+#pragma unroll
+                    for (int it = 0; it < 5; ++it) {
+                        const int mid = (lo + hi + 1) >> 1;
+                        const uint2 c = seg[mid];
+                        if (c.y <= e) { lo = mid; sg = c; } else hi = mid - 1;
+                    }
+                    const unsigned j = sg.x + (e - sg.y);
+                    take_point(G.pts[j], j, qx, qy, qz, best, bid, bpos);
+                }
+                __builtin_amdgcn_wave_barrier();
             }
         }
 #pragma unroll

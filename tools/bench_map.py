@@ -1,6 +1,6 @@
 """Scan-to-map leg on one GPU: a map tiled from synthetic sweeps along a straight
 trajectory, one 120k-point scan registered against it (point-to-point, exact neighbours within 0.4 m).
-    python tools/bench_map.py [n_sweeps]"""
+    python tools/bench_map.py [n_sweeps] [quick]      (quick: without the sweep over cell sizes)"""
 import os
 import sys
 import time
@@ -39,6 +39,8 @@ g.set_source(scan)
 ms = min(g.query(return_kernel_ms=True, distance_upper_bound=0.4)[2] for _ in range(3))
 print(f"bounded NN of the scan: {ms * 1e3:.1f} us = {len(scan) / ms / 1e3:.0f} M queries/s")
 reg.close()
+if len(sys.argv) > 2 and sys.argv[2] == "quick":
+    sys.exit(0)
 from pointcloudprocessing_amd.cell_grid import CellGrid  # noqa: E402
 g = CellGrid(world_pts[:1000], cell=1.0)
 for cell in (0.05, 0.1, 0.15, 0.25, 0.5, 1.0):
