@@ -391,6 +391,7 @@ __global__ void __launch_bounds__(256) k_grid_nn32(const Nn32Args A) {
     int k = max(outside(cx, G.ex), max(outside(cy, G.ey), outside(cz, G.ez)));
     const int k1 = max(reach(cx, G.ex), max(reach(cy, G.ey), reach(cz, G.ez)));
     bool live = has && owned && G.n != 0 && k <= k1;     // uniform over the half-wave
+    int walked = k;                // cells nearer than this many cells (Chebyshev) were walked by earlier passes
     while (live) {
         const int z0 = max(cz - k, 0), z1 = min(cz + k, G.ez - 1);
         const int y0 = max(cy - k, 0), y1 = min(cy + k, G.ey - 1);
@@ -412,8 +413,15 @@ __global__ void __launch_bounds__(256) k_grid_nn32(const Nn32Args A) {
                 const long long p = p0 + sub;
                 unsigned start = 0, count = 0;
                 if (p < total) {
-                    const int x = x0 + (int)(p % nx), y = y0 + (int)((p / nx) % ny), z = z0 + (int)(p / (nx * ny));
-                    if (max(abs(x - cx), max(abs(y - cy), abs(z - cz))) >= k) {      // not an earlier shell
+                    int x, y, z;
+                    if (total <= 0x7fffffffll) {        // 32-bit division where it suffices (64-bit is emulated)
+                        const unsigned pu = (unsigned)p, ux = (unsigned)nx, uxy = (unsigned)(nx * ny);
+                        const unsigned zz = pu / uxy, r = pu - zz * uxy, yy = r / ux;
+                        x = x0 + (int)(r - yy * ux); y = y0 + (int)yy; z = z0 + (int)zz;
+                    } else {
+                        x = x0 + (int)(p % nx); y = y0 + (int)((p / nx) % ny); z = z0 + (int)(p / (nx * ny));
+                    }
+                    if (max(abs(x - cx), max(abs(y - cy), abs(z - cz))) >= walked) {      // not an earlier shell
                         const double gx = axis_gap(qx, (double)(x + G.cminx) * G.cell, (double)(x + G.cminx + 1) * G.cell, G.eps);
                         const double gy = axis_gap(qy, (double)(y + G.cminy) * G.cell, (double)(y + G.cminy + 1) * G.cell, G.eps);
                         const double gz = axis_gap(qz, (double)(z + G.cminz) * G.cell, (double)(z + G.cminz + 1) * G.cell, G.eps);
@@ -434,7 +442,7 @@ __global__ void __launch_bounds__(256) k_grid_nn32(const Nn32Args A) {
                 seg[sub] = make_uint2(start, inc - count);
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
-                for (unsigned e = sub; e < tot; e += 32) {
+                auto locate = [&](const unsigned e) {                       // point e of the dealt list
                     int lo = 0, hi = 31;                                     // last cell whose offset is <= e
                     uint2 sg = seg[0];
 #pragma unroll
@@ -443,8 +451,14 @@ __global__ void __launch_bounds__(256) k_grid_nn32(const Nn32Args A) {
                         const uint2 c = seg[mid];
                         if (c.y <= e) { lo = mid; sg = c; } else hi = mid - 1;
                     }
-                    const unsigned j = sg.x + (e - sg.y);
-                    take_point(G.pts[j], j, qx, qy, qz, best, bid, bpos);
+                    return sg.x + (e - sg.y);
+                };
+                for (unsigned e = sub; e < tot; e += 64) {                   // two points in flight per lane
+                    const bool two = e + 32 < tot;
+                    const unsigned j1 = locate(e), j2 = two ? locate(e + 32) : j1;
+                    const GridPoint p1 = G.pts[j1], p2 = G.pts[j2];
+                    take_point(p1, j1, qx, qy, qz, best, bid, bpos);
+                    if (two) take_point(p2, j2, qx, qy, qz, best, bid, bpos);
                 }
                 __builtin_amdgcn_wave_barrier();
             }
@@ -461,6 +475,7 @@ __global__ void __launch_bounds__(256) k_grid_nn32(const Nn32Args A) {
         const double mz = fmin(qz - (double)(az - k) * G.cell, (double)(az + k + 1) * G.cell - qz);
         const double mrg = fmin(mx, fmin(my, mz)) - G.eps;
         ++k;
+        walked = k;
         if ((mrg > 0.0 && best < mrg * mrg) || k > k1) live = false;
     }
     if (has && sub == 0) {
