@@ -87,6 +87,7 @@ class ComputeShader:
         self.lens_data = np.array([len(points_a), len(points_b), len(scan_lines), 0]).astype(np.uint32)
 
     def _set_target(self, points_a, scan_lines4, origin):
+        self.target_serial = getattr(self, "target_serial", 0) + 1      # every upload of a target counts
         a4 = self.pad_points(points_a)
         lines = np.ascontiguousarray(scan_lines4, dtype=np.uint32)
         o4 = np.resize(origin, (4,)).astype(np.float32)
@@ -128,6 +129,14 @@ class ComputeShader:
         scan_lines = self.padScanlines(scan_lines)
         self.saveUniformInfo(points_a, points_b, origin, scan_lines, debug_mode)
         self._active = "plane"
+
+    def resetHints(self, n_points_b=None):
+        """What every prepare* does to the ring hints (corr.w = -1, ComputeShader.py:488-489,
+        :502-503) without touching the target: for callers that register several clouds against
+        one prepared target."""
+        check(self._lib.pcp_reset_hints(self._ctx))
+        if n_points_b is not None:
+            self.lens_data[1] = n_points_b
 
     def dispatchPointPlane(self, points_b):
         """:587-608 -> (H, b)."""

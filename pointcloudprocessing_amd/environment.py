@@ -41,6 +41,10 @@ class EnvironmentConstructor:
         self.voxelizer.init(voxel_size)
         self.reference_points = None
         self.prev_origin = None
+        # the reference cloud is a new array every reset_origin_treshold frames and never changed in
+        # place here, so the container may keep it prepared on the device between frames
+        if hasattr(self.icp, "keep_prepared_target"):
+            self.icp.keep_prepared_target = True
         self.inited = True
 
     def cleanup(self):

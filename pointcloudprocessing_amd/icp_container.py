@@ -16,6 +16,12 @@ class PointcloudIcpContainer:
     def __init__(self, computeShader, pointcloudAlignment=None):
         self.compute = computeShader
         self.pointcloudAlignment = pointcloudAlignment
+        # Opt-in: full_pt2pt / full_pt2pl skip scan lines, upload and normals when called again with
+        # the SAME array object as `aligned` (and the same origin and mode) and nothing else has
+        # uploaded a target to the compute object in between.  The caller promises not to change
+        # that array in place.  The reference prepares every call (PointcloudIcpContainer.py:72,104).
+        self.keep_prepared_target = False
+        self._kept = None
 
     # ------------------------------------------------------------------ scan lines (:349-392)
     def sphereProjectPont(self, point, origin):
@@ -99,9 +105,25 @@ class PointcloudIcpContainer:
         R_opt, t_opt = self.uniform_optimal_icp(grid, self.getUniformGrid(10))
         return t_opt, R_opt
 
+    def _keep(self, aligned, origin, mode):
+        self._kept = (aligned, np.array(origin, dtype=np.float64), mode, getattr(self.compute, "target_serial", None))
+
+    def _target_kept(self, aligned, origin, mode, to_align):
+        """True when the prepared target on the device is still `aligned` (keep_prepared_target);
+        the ring hints are then reset as a prepare would."""
+        k = self._kept
+        if not (self.keep_prepared_target and k is not None and k[0] is aligned and k[2] == mode
+                and k[3] is not None and k[3] == getattr(self.compute, "target_serial", None)
+                and np.array_equal(k[1], np.asarray(origin, dtype=np.float64))):
+            return False
+        self.compute.resetHints(len(to_align))
+        return True
+
     def full_pt2pt(self, aligned, to_align, origin, iterations=20, renderer=None):
         """:71-100 -> (t_opt, R_opt); exactly `iterations` steps."""
-        self.preparePointToPoint(aligned, origin, to_align)
+        if not self._target_kept(aligned, origin, "point", to_align):
+            self.preparePointToPoint(aligned, origin, to_align)
+            self._keep(aligned, origin, "point")
         if renderer is not None:
             return self._full_stepwise(to_align, iterations, renderer, plane=False, full_iter=True)
         dx, _, _, _ = self.compute.icpRun(to_align, MODE_POINT, iterations)
@@ -109,7 +131,9 @@ class PointcloudIcpContainer:
 
     def full_pt2pl(self, aligned, to_align, origin, iterations=20, renderer=None, full_iter=False):
         """:103-144 -> (t_opt, R_opt); stops when mean|dx| < 1e-6 unless full_iter."""
-        self.preparePointToPlane(aligned, origin, to_align)
+        if not self._target_kept(aligned, origin, "plane", to_align):
+            self.preparePointToPlane(aligned, origin, to_align)
+            self._keep(aligned, origin, "plane")
         if renderer is not None:
             return self._full_stepwise(to_align, iterations, renderer, plane=True, full_iter=full_iter)
         dx, converged, _, _ = self.compute.icpRun(to_align, MODE_PLANE, iterations, tol=1e-6, full_iter=full_iter)

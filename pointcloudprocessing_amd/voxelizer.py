@@ -143,7 +143,15 @@ class Voxelizer:
     def _grow(self):
         """:238-252 -- double table, data and statistics."""
         self.voxel_index = np.vstack([self.voxel_index, np.full_like(self.voxel_index, self.bigint)])
-        self.voxel_data = np.vstack([self.voxel_data, np.zeros_like(self.voxel_data)])
+        # Rows past stored_voxels are zero, so only the used rows are carried over into a freshly
+        # zeroed (lazily mapped) array; when the device holds the authoritative rows the host copy is
+        # stale anyway and will be read back before anybody looks at it, so only the counts move.
+        old, used = self.voxel_data, self.stored_voxels
+        self.voxel_data = np.zeros((2 * len(old), old.shape[1]), dtype=old.dtype)
+        if getattr(self, "_rows_stale", False):
+            self.voxel_data[:used, 0] = old[:used, 0]
+        else:
+            self.voxel_data[:used] = old[:used]
         fresh = np.zeros_like(self.voxel_stats)
         fresh[:, 0] = 0.5
         self.voxel_stats = np.vstack([self.voxel_stats, fresh])
@@ -211,9 +219,16 @@ class Voxelizer:
         if self.added_points is None:
             self.added_points = np.empty((n * 2, 4), dtype=np.float32)
             self.added_colors = np.empty((n * 2, 3), dtype=np.float32)
-        while self.last_added_point + n >= len(self.added_points):
-            self.added_points = np.vstack([self.added_points, np.empty_like(self.added_points)])
-            self.added_colors = np.vstack([self.added_colors, np.empty_like(self.added_colors)])
+        if self.last_added_point + n >= len(self.added_points):
+            size = len(self.added_points)
+            while self.last_added_point + n >= size:       # doubling, as the reference does
+                size *= 2
+            used = self.last_added_point
+            for name in ("added_points", "added_colors"):  # only the rows in use are carried over
+                old = getattr(self, name)
+                new = np.empty((size, old.shape[1]), dtype=old.dtype)
+                new[:used] = old[:used]
+                setattr(self, name, new)
         self.added_points[self.last_added_point:self.last_added_point + n, :3] = np_points[:, :3]
         self.added_colors[self.last_added_point:self.last_added_point + n] = colors
         self.last_added_point += n

@@ -210,6 +210,38 @@ def test_stepwise_protocol_equals_device_loop(compute):
     _pose_close(t1, R1, t2, R2)
 
 
+def test_kept_target_gives_the_poses_of_a_fresh_prepare(compute):
+    """keep_prepared_target: a second registration against the same target array skips the upload
+    and must still equal a registration that prepared from scratch; anything else that uploads a
+    target, another array or another origin ends the reuse."""
+    a, b = small_pair()
+    _, b2 = small_pair(seed=3)
+    fresh = PointcloudIcpContainer(compute)
+    want = [fresh.full_pt2pl(a, s, ORIGIN, iterations=8) for s in (b, b2, b)]
+    want_pt = fresh.full_pt2pt(a, b2, ORIGIN, iterations=5)
+    icp = PointcloudIcpContainer(compute)
+    icp.keep_prepared_target = True
+    serial0 = compute.target_serial
+    got = [icp.full_pt2pl(a, s, ORIGIN, iterations=8) for s in (b, b2, b)]
+    assert compute.target_serial == serial0 + 1                      # one upload for the three runs
+    for (t, R), (wt, wR) in zip(got, want):
+        assert np.array_equal(t, wt) and np.array_equal(R, wR)
+    t, R = icp.full_pt2pt(a, b2, ORIGIN, iterations=5)               # another mode prepares again
+    assert compute.target_serial == serial0 + 2
+    assert np.array_equal(t, want_pt[0]) and np.array_equal(R, want_pt[1])
+    icp.full_pt2pt(a.copy(), b2, ORIGIN, iterations=1)               # an equal but different array too
+    assert compute.target_serial == serial0 + 3
+    a2 = a.copy()
+    icp.full_pt2pl(a2, b, ORIGIN, iterations=2)
+    fresh.preparePointToPlane(a, ORIGIN, b)                          # somebody else used the compute object
+    n = compute.target_serial
+    t, R = icp.full_pt2pl(a2, b, ORIGIN, iterations=8)
+    assert compute.target_serial == n + 1
+    assert np.array_equal(t, want[0][0]) and np.array_equal(R, want[0][1])
+    icp.full_pt2pl(a2, b, np.array([0.0, 0.0, 0.1]), iterations=2)   # another origin
+    assert compute.target_serial == n + 2
+
+
 def test_batched_pairs_equal_single_pair_runs():
     """pcp_batch_icp_launch on three pairs of different sizes (one of them converging early)
     reproduces pcp_icp_run pair by pair, bit for bit."""
