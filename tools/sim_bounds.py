@@ -1,0 +1,100 @@
+"""What a sharper ring bound would buy: simulates the ring visiting order of find_closest on the bench
+workload (all-rings first iteration) with the elevation-band bound the kernels use and with a bound
+that also uses the range band of the ring's points near the query's azimuth.  CPU only.
+    python tools/sim_bounds.py [every_nth_wave]"""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import np_oracle as O  # noqa: E402
+from bench import base_cloud, moved_copy  # noqa: E402
+
+NB = 64
+step = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+a, _ = base_cloud()
+b, R, t = moved_copy(a, 0)
+o = np.zeros(3)
+lines = O.get_scan_lines(a, o)
+Z = len(lines)
+a4, b4, o4 = O.pad_points(a), O.pad_points(b), O.origin4(o)
+ua = O.unit_sphere(a4, o4).astype(np.float64)
+va = a4.astype(np.float64) - np.array([o4[0], o4[1] + 0.127, o4[2], o4[3]])
+rho_a = np.linalg.norm(va, axis=1)
+elev_a = np.arcsin(np.clip(ua[:, 1], -1, 1))
+bin_a = np.clip(((np.arctan2(ua[:, 2], ua[:, 0]) + np.pi) * NB / (2 * np.pi)).astype(int), 0, NB - 1)
+
+# per ring: whole elevation band; per (ring, bin): elevation and range band over bins b-1..b+1
+ring_lo, ring_hi = np.zeros(Z), np.zeros(Z)
+be_lo = np.full((Z, NB), np.inf); be_hi = np.full((Z, NB), -np.inf)
+br_lo = np.full((Z, NB), np.inf); br_hi = np.full((Z, NB), -np.inf)
+for r, (s, e) in enumerate(lines):
+    sl = slice(s, e + 1)
+    ring_lo[r], ring_hi[r] = elev_a[sl].min(), elev_a[sl].max()
+    for arr_lo, arr_hi, val in ((be_lo, be_hi, elev_a[sl]), (br_lo, br_hi, rho_a[sl])):
+        lo1 = np.full(NB, np.inf); hi1 = np.full(NB, -np.inf)
+        np.minimum.at(lo1, bin_a[sl], val); np.maximum.at(hi1, bin_a[sl], val)
+        arr_lo[r] = np.minimum(lo1, np.minimum(np.roll(lo1, 1), np.roll(lo1, -1)))
+        arr_hi[r] = np.maximum(hi1, np.maximum(np.roll(hi1, 1), np.roll(hi1, -1)))
+
+n_waves = len(b) // 64
+waves = np.arange(0, n_waves, step)
+qi = (waves[:, None] * 64 + np.arange(64)[None, :]).reshape(-1)
+q4 = b4[qi]
+ref = O.unit_sphere(q4, o4)
+vq = q4.astype(np.float64) - np.array([o4[0], o4[1] + 0.127, o4[2], o4[3]])
+rho_q = np.linalg.norm(vq, axis=1)
+elev_q = np.arcsin(np.clip(ref[:, 1].astype(np.float64), -1, 1))
+bin_q = np.clip(((np.arctan2(ref[:, 2].astype(np.float64), ref[:, 0].astype(np.float64)) + np.pi) * NB / (2 * np.pi)).astype(int), 0, NB - 1)
+rxz = np.hypot(vq[:, 0], vq[:, 2])
+far = (rxz * np.sin(0.99 * 2 * np.pi / NB)) ** 2
+
+# ring results for every (query, ring)
+scan = np.asarray(lines, dtype=np.int64)
+D = np.zeros((len(qi), Z))
+for r in range(Z):
+    beg = np.full(len(qi), scan[r, 0]); end = np.full(len(qi), scan[r, 1])
+    closest = O.ring_search(O.unit_sphere(a4, o4), ref, beg, end)
+    _, d = O.window_min(a4, q4, beg, end, closest, 10)
+    D[:, r] = d
+
+
+def gap(x, lo, hi):
+    return np.maximum(0.0, np.maximum(lo - x, x - hi))
+
+
+whole = (rho_q[:, None] * np.sin(np.minimum(gap(elev_q[:, None], ring_lo[None, :], ring_hi[None, :]), np.pi / 2))) ** 2
+de = np.minimum(gap(elev_q[:, None], be_lo[:, bin_q].T, be_hi[:, bin_q].T), np.pi / 2)
+none = ~np.isfinite(be_lo[:, bin_q].T)
+near_elev = np.where(none, np.inf, (rho_q[:, None] * np.sin(de)) ** 2)
+sd2 = np.sin(de) ** 2
+rstar = np.clip(rho_q[:, None] * (1 - sd2 / 2), br_lo[:, bin_q].T, br_hi[:, bin_q].T)
+near_both = np.where(none, np.inf, (rho_q[:, None] - rstar) ** 2 + rho_q[:, None] * rstar * sd2)
+centre = np.argmin(whole, axis=1)
+
+
+def simulate(lb, name):
+    Q = len(qi)
+    mind = np.full(Q, np.inf)
+    visits = np.zeros(Q, dtype=int)
+    passes = np.zeros(len(waves), dtype=int)
+    for k in range(2 * Z + 1):
+        off = (k + 1) // 2 if (k & 1) else -(k // 2)
+        r = centre + off
+        ok = (r >= 0) & (r < Z)
+        rr = np.clip(r, 0, Z - 1)
+        want = ok & ((mind == np.inf) | (lb[np.arange(Q), rr] <= mind))
+        d = D[np.arange(Q), rr]
+        mind = np.where(want & (d < mind), d, mind)
+        visits += want
+        passes += want.reshape(len(waves), 64).any(axis=1)
+    print(f"{name:38s}: {visits.mean():5.2f} ring visits per query, {passes.mean():5.2f} passes per wave, "
+          f"{visits.sum() / max(passes.sum(), 1) :5.1f} of 64 lanes per pass")
+    return mind
+
+
+m1 = simulate(np.maximum(whole, np.minimum(near_elev, far[:, None])), "elevation bands (as built)")
+m2 = simulate(np.maximum(whole, np.minimum(near_both, far[:, None])), "elevation + range bands, 3 bins")
+m3 = simulate(D, "perfect knowledge of every ring")
+assert np.array_equal(m1, m2) and np.array_equal(m1, m3)
