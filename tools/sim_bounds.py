@@ -1,7 +1,7 @@
 """What a sharper ring bound would buy: simulates the ring visiting order of find_closest on the bench
 workload (all-rings first iteration) with the elevation-band bound the kernels use and with a bound
 that also uses the range band of the ring's points near the query's azimuth.  CPU only.
-    python tools/sim_bounds.py [every_nth_wave]"""
+    python tools/sim_bounds.py [every_nth_wave] [kitti]"""
 import os
 import sys
 
@@ -13,8 +13,13 @@ from bench import base_cloud, moved_copy  # noqa: E402
 
 NB = 64
 step = int(sys.argv[1]) if len(sys.argv) > 1 else 16
-a, _ = base_cloud()
-b, R, t = moved_copy(a, 0)
+if len(sys.argv) > 2 and sys.argv[2] == "kitti":        # the two real consecutive frames of the fixture
+    from pointcloudprocessing_amd import lidar
+    g = np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "kitti_pair.npz"))
+    a, b = lidar.frame_from_raw(g["raw0"]), lidar.frame_from_raw(g["raw1"])
+else:
+    a, _ = base_cloud()
+    b, R, t = moved_copy(a, 0)
 o = np.zeros(3)
 lines = O.get_scan_lines(a, o)
 Z = len(lines)
@@ -89,12 +94,39 @@ def simulate(lb, name):
         mind = np.where(want & (d < mind), d, mind)
         visits += want
         passes += want.reshape(len(waves), 64).any(axis=1)
-    print(f"{name:38s}: {visits.mean():5.2f} ring visits per query, {passes.mean():5.2f} passes per wave, "
+    print(f"{name:38s}: {visits.mean():5.2f} ring visits per query, {passes.mean():5.2f} passes per wave "
+          f"(slowest wave {passes.max()}, 99th percentile {np.percentile(passes, 99):.0f}), "
           f"{visits.sum() / max(passes.sum(), 1) :5.1f} of 64 lanes per pass")
     return mind
 
 
+def level(width):
+    """Bound from the bands over bins b-width..b+width: min(near points' elevation and range, the rest's azimuth gap)."""
+    e_lo = np.full((Z, NB), np.inf); e_hi = np.full((Z, NB), -np.inf)
+    r_lo = np.full((Z, NB), np.inf); r_hi = np.full((Z, NB), -np.inf)
+    for r, (s, e) in enumerate(lines):
+        sl = slice(s, e + 1)
+        for arr_lo, arr_hi, val in ((e_lo, e_hi, elev_a[sl]), (r_lo, r_hi, rho_a[sl])):
+            lo1 = np.full(NB, np.inf); hi1 = np.full(NB, -np.inf)
+            np.minimum.at(lo1, bin_a[sl], val); np.maximum.at(hi1, bin_a[sl], val)
+            arr_lo[r] = np.min([np.roll(lo1, k) for k in range(-width, width + 1)], axis=0)
+            arr_hi[r] = np.max([np.roll(hi1, k) for k in range(-width, width + 1)], axis=0)
+    d_e = np.minimum(gap(elev_q[:, None], e_lo[:, bin_q].T, e_hi[:, bin_q].T), np.pi / 2)
+    nn = ~np.isfinite(e_lo[:, bin_q].T)
+    s2 = np.sin(d_e) ** 2
+    with np.errstate(invalid="ignore"):
+        rs = np.clip(rho_q[:, None] * (1 - s2 / 2), r_lo[:, bin_q].T, r_hi[:, bin_q].T)
+        both = np.where(nn, np.inf, (rho_q[:, None] - rs) ** 2 + rho_q[:, None] * rs * s2)
+    ang = min(0.99 * width * 2 * np.pi / NB, np.pi / 2)
+    return np.minimum(both, ((rxz * np.sin(ang)) ** 2)[:, None])
+
+
 m1 = simulate(np.maximum(whole, np.minimum(near_elev, far[:, None])), "elevation bands (as built)")
+l1, l2, l4, l8 = level(1), level(2), level(4), level(8)
+simulate(np.maximum(whole, np.maximum(l1, l2)), "range bands, widths 1+2")
+simulate(np.maximum(whole, np.maximum(np.maximum(l1, l2), l4)), "range bands, widths 1+2+4")
+simulate(np.maximum(whole, np.maximum(np.maximum(l1, l4), l8)), "range bands, widths 1+4+8")
+simulate(np.maximum(whole, np.maximum(np.minimum(near_elev, far[:, None]), l4)), "as built + range bands width 4")
 m2 = simulate(np.maximum(whole, np.minimum(near_both, far[:, None])), "elevation + range bands, 3 bins")
 m3 = simulate(D, "perfect knowledge of every ring")
 assert np.array_equal(m1, m2) and np.array_equal(m1, m3)
