@@ -38,6 +38,7 @@ struct pcp_ctx {
     float *tiles = nullptr, *tiles2 = nullptr;        // lazily allocated
     float4 origin = {0, 0, 0, 0};
     int n_a = 0, n_b = 0, n_scans = 0;
+    int n_scans_search = 0;        // rings [n_scans_search, n_scans) repeat ring n_scans_search - 1 (padding)
     bool have_target = false, have_normals = false;
     int run_mode = 0, run_max_iter = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;

@@ -90,6 +90,7 @@ struct Target {
     gf4_t bins;                      // [azimuth bin][ring]: the same for the ring's points in bins b-1, b, b+1
     int n_a;
     int Z;                           // lens_data.z
+    int Zs;                          // rings [Zs, Z) are copies of ring Zs - 1 (the padding rows of the table)
     float4 o;
 };
 
@@ -246,7 +247,9 @@ __device__ __forceinline__ int find_closest(const Target& T, const float4 q, flo
     const float far = (v.x * v.x + v.z * v.z) * PCP_AZ_FAR;
     float mind = PCP_BIG;
     int glob = 0, ring = -1;
-    int from = 0, to = T.Z, centre = 0;
+    // An all-rings search stops at Zs: a copy of a ring returns the same point at the same distance,
+    // and of equal results the lowest ring wins, so the copies can never change (point, ring).
+    int from = 0, to = T.Zs, centre = 0;
     if (hint != -1.0f) {
         const int h = (int)hint;
         from = max(0, h - 2);
@@ -259,7 +262,7 @@ __device__ __forceinline__ int find_closest(const Target& T, const float4 q, flo
             if (lb < lo) { lo = lb; centre = r; }
         }
     }
-    const int span = to - from;
+    const int last = 2 * max(centre - from, to - 1 - centre);       // offset index of this lane's farthest ring
 #ifdef PCP_STATS
     const int sbase = (hint != -1.0f) ? 0 : 4;
     if (__ffsll((long long)__ballot(true)) - 1 == (int)(threadIdx.x & 63)) atomicAdd(&pcp_stats[sbase + 2], 1ull);
@@ -267,7 +270,7 @@ __device__ __forceinline__ int find_closest(const Target& T, const float4 q, flo
     // All lanes step through the offsets 0, +1, -1, +2, ... together: lanes of a wave mostly share
     // their centre ring, so a pass gathers from one ring and coalesces.  (Letting each lane jump to
     // its own next unpruned ring saves 10 % of the passes and costs 30 % in time: measured.)
-    for (int k = 0; k <= 2 * span; ++k) {
+    for (int k = 0; k <= last; ++k) {
         const int r = centre + ((k & 1) ? (k + 1) / 2 : -(k / 2));      // c, c+1, c-1, c+2, c-2, ...
         if (r < from || r >= to) continue;
         if (can_prune && mind < PCP_BIG) {

@@ -140,7 +140,7 @@ __global__ void __launch_bounds__(64) k_ring_stats_batch(const PrepArgs* __restr
 // NearestNeighbourScan.glsl:1-35.  One wave per block = one shader workgroup.
 __global__ void __launch_bounds__(PCP_BLOCK)
 k_nn(const float4* __restrict__ a, const float4* __restrict__ ua, const int2* __restrict__ scan,
-     const float4* __restrict__ stat, const float4* __restrict__ bins, int n_a, int Z, float4 o,
+     const float4* __restrict__ stat, const float4* __restrict__ bins, int n_a, int Z, int Zs, float4 o,
      const float4* __restrict__ b, int n_b, float* __restrict__ hint, uint32_t* __restrict__ idx,
      float* __restrict__ dist) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -149,7 +149,7 @@ k_nn(const float4* __restrict__ a, const float4* __restrict__ ua, const int2* __
     load_rings(smem, scan, stat, Z, s_scan, s_stat);
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const bool in = i < n_b;
-    const Target T{as_global(a), as_global(ua), s_scan, s_stat, as_global(bins), n_a, Z, o};
+    const Target T{as_global(a), as_global(ua), s_scan, s_stat, as_global(bins), n_a, Z, Zs, o};
     const float4 q = in ? b[i] : make_float4(0.f, 0.f, 0.f, 0.f);
     float h = in ? hint[i] : -1.0f;
     if (!in) return;
@@ -197,7 +197,7 @@ __device__ __forceinline__ void normals_body(const float4* __restrict__ a, const
     load_rings(smem, scan, stat, Z, s_scan, s_stat);
     const int i = block * blockDim.x + threadIdx.x;
     if (i >= n_a) return;
-    const Target T{as_global(a), as_global(ua), s_scan, s_stat, nullptr, n_a, Z, o};
+    const Target T{as_global(a), as_global(ua), s_scan, s_stat, nullptr, n_a, Z, Z, o};
     // getScanLineOfPoint, NormalShader.glsl:1-10: first ring that contains the point
     int ring = -1;
     for (int r = 0; r < Z; ++r) {
@@ -261,7 +261,7 @@ __global__ void __launch_bounds__(PCP_BLOCK) __attribute__((amdgpu_waves_per_eu(
 //           (apply_iteration_of_ls, PointcloudIcpContainer.py:172-174).
 struct LsArgs {
     const float4* a; const float4* ua; const int2* scan; const float4* stat; const float4* bins;
-    int n_a, Z; float4 o;
+    int n_a, Z, Zs; float4 o;
     const float4* normals; const float4* b32; const double* b_in; double* b64; IcpState* st;
     int n_b, debug;
     float* hint; float* partials; float* tiles;
@@ -309,7 +309,7 @@ __device__ __forceinline__ void ls_body(const LsArgs& A, char* smem, const unsig
             q = A.b32[i];
         }
     }
-    const Target T{as_global(a), as_global(A.ua), s_scan, s_stat, as_global(A.bins), A.n_a, A.Z, A.o};
+    const Target T{as_global(a), as_global(A.ua), s_scan, s_stat, as_global(A.bins), A.n_a, A.Z, A.Zs, A.o};
     int nn = in ? i : 0;      // debug_info.x >= 1: identity correspondences, LeastSquaresPoint.glsl:78-81
     float d = 0.0f;
     if (!debug) {
@@ -485,7 +485,7 @@ LsArgs ls_args(const pcp_ctx* c, int debug, float* tiles) {
     LsArgs A;
     memset(&A, 0, sizeof(A));          // padding bytes too: descriptors are compared with memcmp
     A.a = c->a; A.ua = c->ua; A.scan = c->scan; A.stat = c->ring_stat; A.bins = c->ring_bins;
-    A.n_a = c->n_a; A.Z = c->n_scans; A.o = c->origin;
+    A.n_a = c->n_a; A.Z = c->n_scans; A.Zs = c->n_scans_search; A.o = c->origin;
     A.normals = c->normals; A.b32 = c->b32; A.b_in = c->b_in; A.b64 = c->b64; A.st = c->state;
     A.n_b = c->n_b; A.debug = debug;
     A.hint = c->hint; A.partials = c->partials; A.tiles = tiles;
@@ -704,6 +704,9 @@ static int set_target_impl(pcp_ctx* c, const float* a_xyzw, int n_a, const uint3
     c->origin = make_float4(origin4[0], origin4[1], origin4[2], origin4[3]);
     c->n_a = n_a;
     c->n_scans = n_scans;
+    int zs = n_scans;              // trailing rows equal to the row before them are padding copies
+    while (zs > 1 && lines[zs - 1].x == lines[zs - 2].x && lines[zs - 1].y == lines[zs - 2].y) --zs;
+    c->n_scans_search = zs;
     c->have_target = true;
     return pcp_prepare_resident(c, 0);
 }
@@ -728,7 +731,7 @@ int pcp_nn(pcp_ctx* c, const float* b_xyzw, int n_b, uint32_t* idx, float* dist2
     if (!idx || !dist2) return pcp_fail("null output");
     if (int e = upload_b32(c, b_xyzw, n_b)) return e;
     hipLaunchKernelGGL(k_nn, dim3(cdiv(n_b, PCP_BLOCK)), dim3(PCP_BLOCK), scan_smem(c), c->stream, c->a, c->ua, c->scan, c->ring_stat, c->ring_bins,
-                       c->n_a, c->n_scans, c->origin, c->b32, n_b, c->hint, c->nn_idx, c->nn_dist);
+                       c->n_a, c->n_scans, c->n_scans_search, c->origin, c->b32, n_b, c->hint, c->nn_idx, c->nn_dist);
     PCP_CHECK(hipGetLastError());
     PCP_CHECK(hipMemcpyAsync(idx, c->nn_idx, (size_t)n_b * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
     PCP_CHECK(hipMemcpyAsync(dist2, c->nn_dist, (size_t)n_b * sizeof(float), hipMemcpyDeviceToHost, c->stream));
