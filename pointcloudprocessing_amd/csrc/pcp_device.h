@@ -345,9 +345,20 @@ __device__ __forceinline__ void ls_plane_values(const float4 pa, const float4 pb
 
 // The pairwise tree of ParalellHBSum.glsl:158-164 over the 64 lanes of a wave:
 // after the six steps lane 0 holds exactly sdata[0] of the shader.
+// Only the lanes below s matter at step s, and they read lanes below 2s, so what the other lanes
+// receive is irrelevant.  Steps 32 and 16 are the gfx950 half-wave and row swaps (lane l of the
+// second result holds lane l + 32, resp. l + 16 for the even rows, of the operand), steps 8..1 are
+// row shifts applied inside the addition (DPP): no LDS traffic at all.
 __device__ __forceinline__ float wave_tree_sum(float x) {
-#pragma unroll
-    for (int s = 32; s > 0; s >>= 1) x = x + __shfl_down(x, s, 64);
+    typedef unsigned pcp_u2 __attribute__((ext_vector_type(2)));
+    pcp_u2 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    x = x + __uint_as_float(r.y);
+    r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    x = x + __uint_as_float(r.y);
+    x = x + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x108, 0xf, 0xf, true));   // row_shl:8
+    x = x + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x104, 0xf, 0xf, true));   // row_shl:4
+    x = x + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x102, 0xf, 0xf, true));   // row_shl:2
+    x = x + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x101, 0xf, 0xf, true));   // row_shl:1
     return x;
 }
 
