@@ -39,7 +39,7 @@ int pcp_version(void);
 int pcp_device_count(int* count);
 
 /* ComputeShader.__init__ (:13-98) + prepareBuffers (:124-203): device buffers
- * for clouds of at most max_points points and max_scans scan lines. */
+ * for clouds of at most max_points points (<= 2^24) and max_scans scan lines (<= 2048). */
 int pcp_create(int device, int max_points, int max_scans, pcp_ctx** out);
 /* ComputeShader.cleanup (:966-998). */
 int pcp_destroy(pcp_ctx* ctx);

@@ -570,7 +570,8 @@ int pcp_create(int device, int max_points, int max_scans, pcp_ctx** out) {
     *out = nullptr;
     if (max_points < 1 || max_points > (1 << 24))
         return pcp_fail("max_points = %d outside [1, 2^24] (indices travel as float32 in the reference)", max_points);
-    if (max_scans < 1 || max_scans > 4096) return pcp_fail("max_scans = %d outside [1, 4096]", max_scans);
+    // every search block keeps the ring table (24 bytes per ring) in its 64 KB of dynamic LDS
+    if (max_scans < 1 || max_scans > 2048) return pcp_fail("max_scans = %d outside [1, 2048]", max_scans);
     int ndev = 0;
     PCP_CHECK(hipGetDeviceCount(&ndev));
     if (device < 0 || device >= ndev) return pcp_fail("device %d not present (%d visible)", device, ndev);

@@ -389,3 +389,41 @@ def test_ragged_ring_layouts_match_oracle_bitwise(compute, seed):
     H, bb = compute.dispatchPointPlane(b)
     rH, rb = spl.dispatch_plane(b)
     assert np.array_equal(bits(H), bits(rH)) and np.array_equal(bits(bb), bits(rb))
+
+
+# ------------------------------------------------------------------------------ largest ring table
+def test_two_thousand_rings_match_oracle_bitwise():
+    """maxScans at the library's limit (2048 table rows, 1,500 of them real rings of 3 to 40 points): the
+    ring table fills most of a block's LDS.  NN over all rings and hinted, and the plane tile sum."""
+    from pointcloudprocessing_amd import ComputeShader, PcpError
+    rng = np.random.default_rng(7)
+    lengths = rng.integers(3, 41, 1500)
+    ends = np.cumsum(lengths)
+    lines = [(int(e - L), int(e - 1)) for L, e in zip(lengths, ends)]
+    n_a = int(ends[-1])
+    el = np.repeat(np.linspace(-0.4, 0.3, len(lengths)), lengths) + rng.normal(0, 1e-3, n_a)
+    az = np.concatenate([np.sort(rng.uniform(-np.pi, np.pi, L)) for L in lengths])
+    rg = rng.uniform(4.0, 30.0, n_a)
+    a = np.column_stack([rg * np.cos(el) * np.cos(az), rg * np.sin(el) + 0.127, rg * np.cos(el) * np.sin(az)])
+    b = a[rng.integers(0, n_a, 700)] + rng.normal(0, 0.03, (700, 3))
+    with pytest.raises(PcpError):
+        ComputeShader(maxPointsPerCloud=n_a, maxScans=2049)
+    cs = ComputeShader(maxPointsPerCloud=n_a, maxScans=2048)
+    try:
+        st = O.RingIcp(2048)
+        st.prepare_nns(a, lines, ORIGIN)
+        cs.prepareNNS(a, lines, b, ORIGIN)
+        for call in range(2):
+            idx, dist = cs.dispatchNNS(b)
+            ridx, rdist = st.dispatch_nns(b)
+            assert np.array_equal(idx, ridx), f"call {call}"
+            assert np.array_equal(bits(dist), bits(rdist)), f"call {call}"
+            assert np.array_equal(bits(cs.corr_out[:, 3]), bits(st.hint)), f"call {call}"
+        spl = O.RingIcp(2048)
+        spl.prepare_plane(a, lines, ORIGIN)
+        cs.preparePointPlane(a, lines, b, ORIGIN)
+        H, bb = cs.dispatchPointPlane(b)
+        rH, rb = spl.dispatch_plane(b)
+        assert np.array_equal(bits(H), bits(rH)) and np.array_equal(bits(bb), bits(rb))
+    finally:
+        cs.cleanup()
