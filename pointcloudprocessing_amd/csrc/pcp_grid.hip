@@ -78,8 +78,12 @@ __device__ __forceinline__ int cell_of(const double v, const double cell) {
     return (f == f) ? (int)f : COORD_CLAMP;
 }
 
-__device__ __forceinline__ unsigned hash_slot(const unsigned long long key, const int log_cap) {
-    return (unsigned)((key * 0x9E3779B97F4A7C15ull) >> (64 - log_cap));
+// Slot t = 0, 1, 2, ... of a key's probe sequence: multiplicative hash, linear probing.  (Hashing
+// 2 x 2 x 2 blocks of cells to one 128-byte line of the table each, so that the 27 cells of a query
+// lie in at most 8 lines, was measured: builds 10-20 % faster, queries up to 1.8x slower -- the cells of
+// dense blocks fill their lines and every miss or collision walks a whole line.)
+__device__ __forceinline__ unsigned probe_slot(const unsigned long long key, const int log_cap, const unsigned t) {
+    return ((unsigned)((key * 0x9E3779B97F4A7C15ull) >> (64 - log_cap)) + t) & ((1u << log_cap) - 1u);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -142,39 +146,40 @@ k_count_cells(const unsigned long long* __restrict__ keys, size_t n, unsigned lo
     if ((threadIdx.x & 63) == 0 && mine) atomicAdd(count, (unsigned long long)mine);
 }
 
+// One table entry per run of equal keys, written by the thread of the run's last element: it finds
+// the run's first element by doubling steps backwards and a bisection (the keys are sorted), claims
+// a slot and stores (start, count) with one 8-byte write.
 __global__ void k_insert_cells(const unsigned long long* __restrict__ keys, size_t n, Cell* __restrict__ table, int log_cap) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n || (i != 0 && keys[i] == keys[i - 1])) return;
+    if (i >= n || (i + 1 != n && keys[i] == keys[i + 1])) return;
     const unsigned long long key = keys[i];
-    const unsigned mask = (1u << log_cap) - 1u;
-    unsigned slot = hash_slot(key, log_cap);
-    while (true) {
-        const unsigned long long old = atomicCAS(&table[slot].key, EMPTY_KEY, key);
-        if (old == EMPTY_KEY || old == key) { table[slot].start = (unsigned)i; return; }
-        slot = (slot + 1) & mask;
+    long long hi = (long long)i, lo = -1, step = 1;          // keys[hi] == key, keys[lo] != key (lo = -1: before the array)
+    while (hi - step >= 0) {
+        if (keys[hi - step] != key) { lo = hi - step; break; }
+        hi -= step;
+        step <<= 1;
+    }
+    while (hi - lo > 1) {
+        const long long mid = lo + (hi - lo) / 2;
+        if (keys[mid] == key) hi = mid; else lo = mid;
+    }
+    const unsigned long long entry = (unsigned long long)(unsigned)hi | ((unsigned long long)(unsigned)(i + 1 - (size_t)hi) << 32);
+    for (unsigned t = 0;; ++t) {
+        const unsigned slot = probe_slot(key, log_cap, t);
+        if (atomicCAS(&table[slot].key, EMPTY_KEY, key) == EMPTY_KEY) {
+            *reinterpret_cast<unsigned long long*>(&table[slot].start) = entry;
+            return;
+        }
     }
 }
 
 __device__ __forceinline__ bool find_cell(const Cell* __restrict__ table, const int log_cap, const unsigned long long key,
                                           unsigned& start, unsigned& count) {
-    const unsigned mask = (1u << log_cap) - 1u;
-    unsigned slot = hash_slot(key, log_cap);
-    while (true) {
-        const ulonglong2 c = *reinterpret_cast<const ulonglong2*>(&table[slot]);
+    for (unsigned t = 0;; ++t) {
+        const ulonglong2 c = *reinterpret_cast<const ulonglong2*>(&table[probe_slot(key, log_cap, t)]);
         if (c.x == key) { start = (unsigned)c.y; count = (unsigned)(c.y >> 32); return true; }
         if (c.x == EMPTY_KEY) return false;
-        slot = (slot + 1) & mask;
     }
-}
-
-__global__ void k_close_cells(const unsigned long long* __restrict__ keys, size_t n, Cell* __restrict__ table, int log_cap) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n || (i + 1 != n && keys[i] == keys[i + 1])) return;
-    const unsigned long long key = keys[i];
-    const unsigned mask = (1u << log_cap) - 1u;
-    unsigned slot = hash_slot(key, log_cap);
-    while (table[slot].key != key) slot = (slot + 1) & mask;       // inserted by k_insert_cells
-    table[slot].count = (unsigned)(i + 1) - table[slot].start;
 }
 
 __global__ void k_gather_points(const double* __restrict__ xyz, const unsigned* __restrict__ vals, size_t n,
@@ -1144,7 +1149,6 @@ static int build_device(pcp_grid* g, const double* d_xyz, const float4* d_nrm, c
     GRID_TRY(hipMalloc(&g->table, g->table_cap * sizeof(Cell)));
     GRID_TRY(hipMemsetAsync(g->table, 0xFF, g->table_cap * sizeof(Cell), s));
     hipLaunchKernelGGL(k_insert_cells, dim3(blocks_for(n, 256)), dim3(256), 0, s, kin, n, g->table, log_cap);
-    hipLaunchKernelGGL(k_close_cells, dim3(blocks_for(n, 256)), dim3(256), 0, s, kin, n, g->table, log_cap);
     GRID_TRY(hipMalloc(&g->pts, n * sizeof(GridPoint)));
     if (d_nrm) GRID_TRY(hipMalloc(&g->normals, n * 16));
     hipLaunchKernelGGL(k_gather_points, dim3(blocks_for(n, 256)), dim3(256), 0, s, d_xyz, vin, n, d_nrm, d_ids, g->pts, g->normals);
