@@ -13,7 +13,10 @@ constexpr unsigned long long RS_EMPTY_KEY = 0xFFFFFFFFFFFFFFFFull;
 // LSD radix sort, 8 bits per pass, stable.  A block of 4 waves owns a tile of RS_TILE keys, RS_ROUNDS
 // rounds of 64 per wave.  Larger tiles mean fewer per-block histograms to scan.
 constexpr int RS_THREADS = 256;
-constexpr int RS_ROUNDS = 16;
+#ifndef PCP_RS_ROUNDS
+#define PCP_RS_ROUNDS 16
+#endif
+constexpr int RS_ROUNDS = PCP_RS_ROUNDS;
 constexpr int RS_TILE = RS_THREADS * RS_ROUNDS;
 
 static __global__ void __launch_bounds__(RS_THREADS)
@@ -31,27 +34,41 @@ k_rs_hist(const unsigned long long* __restrict__ keys, size_t n, int shift, unsi
     hist[(size_t)threadIdx.x * nblk + blockIdx.x] = h[threadIdx.x];     // digit-major
 }
 
-// Block d: exclusive prefix of hist[d][0..nblk) in place, digit total to totals[d].
-static __global__ void __launch_bounds__(256) k_rs_scan(unsigned* __restrict__ hist, int nblk, unsigned* __restrict__ totals) {
-    __shared__ unsigned s[256];
-    unsigned* h = hist + (size_t)blockIdx.x * nblk;
-    unsigned run = 0;
-    for (int base = 0; base < nblk; base += 256) {
-        const int i = base + threadIdx.x;
-        const unsigned v = (i < nblk) ? h[i] : 0u;
-        s[threadIdx.x] = v;
-        __syncthreads();
-        for (int off = 1; off < 256; off <<= 1) {
-            const unsigned t = (threadIdx.x >= (unsigned)off) ? s[threadIdx.x - off] : 0u;
-            __syncthreads();
-            s[threadIdx.x] += t;
-            __syncthreads();
-        }
-        if (i < nblk) h[i] = run + s[threadIdx.x] - v;
-        run += s[255];
-        __syncthreads();
+// Inclusive prefix sum over the 256 threads of a block (4 waves): DPP-free shuffles inside a wave,
+// the wave totals through LDS.  s4: 4 uints of LDS.  Every thread of the block calls it.
+static __device__ __forceinline__ unsigned block_scan256(unsigned v, unsigned* s4, unsigned& total) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned t = __shfl_up(v, off, 64);
+        if (lane >= off) v += t;
     }
-    if (threadIdx.x == 0) totals[blockIdx.x] = run;
+    __syncthreads();                       // s4 may still be read from an earlier call
+    if (lane == 63) s4[w] = v;
+    __syncthreads();
+    const unsigned a = s4[0], b = s4[1], c = s4[2], d = s4[3];
+    total = a + b + c + d;
+    return v + (w > 0 ? a : 0u) + (w > 1 ? b : 0u) + (w > 2 ? c : 0u);
+}
+
+// Block d: exclusive prefix of hist[d][0..nblk) in place, digit total to totals[d].  Thread t owns
+// a run of consecutive entries: it sums them, the 256 sums are scanned once, and the thread then
+// rewrites its run.
+static __global__ void __launch_bounds__(256) k_rs_scan(unsigned* __restrict__ hist, int nblk, unsigned* __restrict__ totals) {
+    __shared__ unsigned s4[4];
+    unsigned* h = hist + (size_t)blockIdx.x * nblk;
+    const int per = (nblk + 255) / 256;
+    const int lo = min((int)threadIdx.x * per, nblk), hi = min(lo + per, nblk);
+    unsigned sum = 0;
+    for (int i = lo; i < hi; ++i) sum += h[i];
+    unsigned total;
+    unsigned run = block_scan256(sum, s4, total) - sum;
+    for (int i = lo; i < hi; ++i) {
+        const unsigned v = h[i];
+        h[i] = run;
+        run += v;
+    }
+    if (threadIdx.x == 0) totals[blockIdx.x] = total;
 }
 
 static __global__ void __launch_bounds__(256) k_rs_base(const unsigned* __restrict__ totals, unsigned* __restrict__ base) {
@@ -68,28 +85,38 @@ static __global__ void __launch_bounds__(256) k_rs_base(const unsigned* __restri
     base[threadIdx.x] = s[threadIdx.x] - v;
 }
 
-// Each wave ranks its own 64 * RS_ROUNDS consecutive keys (rounds of 64, in order), so
-// the rank of a key among equal digits is: digit base + blocks before + waves
-// before + earlier rounds of this wave + lower lanes of this round.
+// Each wave ranks its own 64 * RS_ROUNDS consecutive keys (rounds of 64, in order), so the rank of
+// a key among the tile's keys of equal digit is: waves before + earlier rounds of this wave + lower
+// lanes of this round.  The tile is then put in digit order in LDS and copied out from there: the
+// keys of one digit leave as one run of consecutive addresses instead of one 8-byte write per key.
 static __global__ void __launch_bounds__(RS_THREADS)
 k_rs_scatter(const unsigned long long* __restrict__ keys_in, const unsigned* __restrict__ vals_in, size_t n, int shift,
              const unsigned* __restrict__ hist, const unsigned* __restrict__ base, int nblk,
              unsigned long long* __restrict__ keys_out, unsigned* __restrict__ vals_out) {
     __shared__ unsigned cnt[4][256];
-    __shared__ unsigned goff[256];
+    __shared__ unsigned tstart[256];       // first place of a digit in the sorted tile
+    __shared__ unsigned delta[256];        // place in the tile -> place in the output, per digit (mod 2^32)
+    __shared__ unsigned s4[4];
+    __shared__ unsigned long long sk[RS_TILE];
+    __shared__ unsigned sv[RS_TILE];
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
     for (int j = tid; j < 4 * 256; j += RS_THREADS) (&cnt[0][0])[j] = 0;
-    goff[tid] = base[tid] + hist[(size_t)tid * nblk + blockIdx.x];
+    const unsigned goff = base[tid] + hist[(size_t)tid * nblk + blockIdx.x];
     __syncthreads();
     unsigned long long k[RS_ROUNDS];
     unsigned v[RS_ROUNDS], loc[RS_ROUNDS];
-    const size_t seg = (size_t)blockIdx.x * RS_TILE + (size_t)w * (64 * RS_ROUNDS);
+    const size_t tile0 = (size_t)blockIdx.x * RS_TILE;
+    const size_t seg = tile0 + (size_t)w * (64 * RS_ROUNDS);
 #pragma unroll
     for (int i = 0; i < RS_ROUNDS; ++i) {
         const size_t j = seg + (size_t)i * 64 + lane;
         const bool valid = j < n;
         k[i] = valid ? keys_in[j] : RS_EMPTY_KEY;
         v[i] = valid ? vals_in[j] : 0u;
+    }
+#pragma unroll
+    for (int i = 0; i < RS_ROUNDS; ++i) {
+        const bool valid = seg + (size_t)i * 64 + lane < n;
         const unsigned digit = (unsigned)(k[i] >> shift) & 255u;
         unsigned long long mask = __ballot(valid);
 #pragma unroll
@@ -110,21 +137,37 @@ k_rs_scatter(const unsigned long long* __restrict__ keys_in, const unsigned* __r
     }
     __syncthreads();
     {
-        const unsigned c0 = cnt[0][tid], c1 = cnt[1][tid], c2 = cnt[2][tid];
+        const unsigned c0 = cnt[0][tid], c1 = cnt[1][tid], c2 = cnt[2][tid], c3 = cnt[3][tid];
         cnt[0][tid] = 0;
         cnt[1][tid] = c0;
         cnt[2][tid] = c0 + c1;
         cnt[3][tid] = c0 + c1 + c2;
+        const unsigned mine = c0 + c1 + c2 + c3;
+        unsigned total;
+        const unsigned first = block_scan256(mine, s4, total) - mine;
+        tstart[tid] = first;
+        delta[tid] = goff - first;
     }
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < RS_ROUNDS; ++i) {
-        const size_t j = seg + (size_t)i * 64 + lane;
-        if (j < n) {
+        if (seg + (size_t)i * 64 + lane < n) {
             const unsigned digit = (unsigned)(k[i] >> shift) & 255u;
-            const size_t pos = (size_t)goff[digit] + cnt[w][digit] + loc[i];
-            keys_out[pos] = k[i];
-            vals_out[pos] = v[i];
+            const unsigned p = tstart[digit] + cnt[w][digit] + loc[i];
+            sk[p] = k[i];
+            sv[p] = v[i];
+        }
+    }
+    __syncthreads();
+    const unsigned in_tile = (unsigned)(n - tile0 < (size_t)RS_TILE ? n - tile0 : (size_t)RS_TILE);
+#pragma unroll
+    for (int i = 0; i < RS_ROUNDS; ++i) {
+        const unsigned p = (unsigned)i * RS_THREADS + tid;
+        if (p < in_tile) {
+            const unsigned long long key = sk[p];
+            const size_t pos = (size_t)(unsigned)(delta[(unsigned)(key >> shift) & 255u] + p);
+            keys_out[pos] = key;
+            vals_out[pos] = sv[p];
         }
     }
 }
