@@ -77,7 +77,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--pairs", type=int, default=16, help="independent frame pairs per GPU per step")
+    ap.add_argument("--pairs", type=int, default=64,
+                    help="independent frame pairs per GPU per step (64 = one GPU's share of a sequence "
+                         "replicated to 8 x 64 pairs)")
     ap.add_argument("--streams", type=int, default=1,
                     help="the pairs of a step are split into this many batches, each on a stream of its own")
     ap.add_argument("--no-cpu-baseline", action="store_true")

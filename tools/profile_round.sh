@@ -15,6 +15,7 @@ cd $R
 python tools/rocpd_export.py stats $O/kt/kt_results.db $O/kernel_stats.csv
 python tools/rocpd_export.py pmc $O/fetch/f_results.db $O/pmc_FETCH_SIZE.csv
 python tools/rocpd_export.py pmc $O/write/w_results.db $O/pmc_WRITE_SIZE.csv
+python tools/make_traffic.py $O/bench_line.json $O/pmc_FETCH_SIZE.csv $O/pmc_WRITE_SIZE.csv $O/traffic.json
 timeout -k 10 100 python tools/bench_hbsum.py > $O/hbsum.txt 2>&1
 timeout -k 10 200 python tools/bench_grid.py > $O/grid_1m.txt 2>&1
 timeout -k 10 300 python tools/bench_grid.py 50000000 > $O/grid_50m.txt 2>&1
