@@ -43,6 +43,7 @@ class ComputeShader:
         self._ctx = C.c_void_p()
         check(self._lib.pcp_create(int(device), int(maxPointsPerCloud), int(maxScans), C.byref(self._ctx)))
         self._active = None          # which prepare* ran last
+        self._n_source = None        # points of the float64 source IcpBatch.upload_sources sent last
         self._voxel_resident = None  # voxel count of a map whose device copy is the authority, else None
         self.reallocate_out(np.array([maxPointsPerCloud, maxPointsPerCloud, 0, 0]))
 
@@ -200,6 +201,7 @@ class ComputeShader:
         iters, conv = C.c_int(0), C.c_int(0)
         check(self._lib.pcp_icp_run(self._ctx, f64p(b), n, int(mode), int(iterations), float(tol), int(full_iter),
                                     f32p(dx), f32p(hb), C.byref(iters), C.byref(conv), f64p(out)))
+        self._n_source = n
         k = iters.value
         return dx[:k], bool(conv.value), (hb[:k] if want_hb else None), out
 
@@ -332,6 +334,7 @@ class IcpBatch:
             b = np.ascontiguousarray(np.asarray(pts)[:, :3], dtype=np.float64)
             check(self._lib.pcp_upload_source(c._ctx, f64p(b), len(b)))
             check(self._lib.pcp_synchronize(c._ctx))
+            c._n_source = len(b)
 
     def prepare(self, with_normals):
         check(self._lib.pcp_batch_prepare(self._batch, int(with_normals)))
@@ -351,8 +354,9 @@ class IcpBatch:
             it, cv = C.c_int(0), C.c_int(0)
             pts = None
             if want_points:
-                n = C.c_int(0)
-                pts = np.empty((int(c.lens_data[1]), 3), dtype=np.float64)
+                if getattr(c, "_n_source", None) is None:
+                    raise PcpError("moved points are only returned for sources uploaded by upload_sources")
+                pts = np.empty((c._n_source, 3), dtype=np.float64)
             check(self._lib.pcp_icp_fetch(c._ctx, f32p(dx), f32p(hb), C.byref(it), C.byref(cv), f64p(pts)))
             out.append((dx[:it.value], bool(cv.value), hb[:it.value] if want_hb else None, pts))
         return out

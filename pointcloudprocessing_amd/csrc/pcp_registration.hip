@@ -968,7 +968,12 @@ int pcp_batch_create(pcp_ctx** ctxs, int n, pcp_batch** out) {
         return 1;
     }
     for (int i = 0; i < n; ++i) {
-        PCP_CHECK(hipStreamSynchronize(ctxs[i]->stream));      // work queued on the old stream comes first
+        e = hipStreamSynchronize(ctxs[i]->stream);             // work queued on the old stream comes first
+        if (e != hipSuccess) {
+            pcp_fail("pcp_batch_create: %s", hipGetErrorString(e));
+            pcp_batch_destroy(b);                              // hands the adopted contexts their own streams back
+            return 1;
+        }
         ctxs[i]->stream = b->stream;
         b->ctxs.push_back(ctxs[i]);
     }
