@@ -96,14 +96,27 @@ __global__ void __launch_bounds__(256)
 k_cell_range(const double* __restrict__ xyz, size_t n, double cell, int* __restrict__ mm) {
     int lo[3] = {INT_MAX, INT_MAX, INT_MAX}, hi[3] = {INT_MIN, INT_MIN, INT_MIN};
     int bad = 0;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    // four points per trip, all twelve loads issued before the first division: a thread's trips are
+    // serial, so the loads in flight per trip set the rate
+    constexpr int U = 4;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i0 < n; i0 += U * stride) {
+        double v[U][3];
 #pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            const double v = xyz[3 * i + a];
-            if (!(fabs(v / cell) < (double)(COORD_BIAS - 2))) bad = 1;
-            const int c = cell_of(v, cell);
-            lo[a] = min(lo[a], c);
-            hi[a] = max(hi[a], c);
+        for (int u = 0; u < U; ++u) {
+            const size_t i = i0 + u * stride;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) v[u][a] = (i < n) ? xyz[3 * i + a] : xyz[3 * i0 + a];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                if (!(fabs(v[u][a] / cell) < (double)(COORD_BIAS - 2))) bad = 1;
+                const int c = cell_of(v[u][a], cell);
+                lo[a] = min(lo[a], c);
+                hi[a] = max(hi[a], c);
+            }
         }
     }
 #pragma unroll
@@ -115,13 +128,21 @@ k_cell_range(const double* __restrict__ xyz, size_t n, double cell, int* __restr
         }
         bad |= __shfl_down(bad, s, 64);
     }
+    // the block's four waves meet in LDS, so that one set of same-address atomics leaves per block
+    __shared__ int part[4][7];
     if ((threadIdx.x & 63) == 0) {
+        int* p = part[threadIdx.x >> 6];
 #pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            atomicMin(&mm[a], lo[a]);
-            atomicMax(&mm[3 + a], hi[a]);
-        }
-        if (bad) atomicOr(&mm[6], 1);
+        for (int a = 0; a < 3; ++a) { p[a] = lo[a]; p[3 + a] = hi[a]; }
+        p[6] = bad;
+    }
+    __syncthreads();
+    if (threadIdx.x < 7) {
+        const int t = threadIdx.x;
+        const int w0 = part[0][t], w1 = part[1][t], w2 = part[2][t], w3 = part[3][t];
+        if (t < 3) atomicMin(&mm[t], min(min(w0, w1), min(w2, w3)));
+        else if (t < 6) atomicMax(&mm[t], max(max(w0, w1), max(w2, w3)));
+        else if (w0 | w1 | w2 | w3) atomicOr(&mm[6], 1);
     }
 }
 
@@ -143,7 +164,13 @@ k_count_cells(const unsigned long long* __restrict__ keys, size_t n, unsigned lo
         mine += (i == 0 || keys[i] != keys[i - 1]) ? 1u : 0u;
 #pragma unroll
     for (int s = 32; s > 0; s >>= 1) mine += __shfl_down(mine, s, 64);
-    if ((threadIdx.x & 63) == 0 && mine) atomicAdd(count, (unsigned long long)mine);
+    __shared__ unsigned part[4];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = mine;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned all = part[0] + part[1] + part[2] + part[3];
+        if (all) atomicAdd(count, (unsigned long long)all);
+    }
 }
 
 // One table entry per run of equal keys, written by the thread of the run's last element: it finds
