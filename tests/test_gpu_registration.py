@@ -427,3 +427,67 @@ def test_two_thousand_rings_match_oracle_bitwise():
         assert np.array_equal(bits(H), bits(rH)) and np.array_equal(bits(bb), bits(rb))
     finally:
         cs.cleanup()
+
+
+# ------------------------------------------------------------------------------ non-finite and degenerate points
+def test_non_finite_and_degenerate_points_match_oracle_bitwise(compute):
+    """Source points that are NaN, infinite, huge, the sensor position itself (zero-length direction) or
+    copies of target points, and a target with runs of identical points (undefined normals, which the plane
+    kernel zeroes like nan_check, LeastSquaresPlane.glsl:18-24): indices, distances, hints, normals and both
+    tile sums against the restatement, bit for bit."""
+    a, b = small_pair()
+    a = a.copy()
+    a[100:104] = a[100]                      # four identical neighbours on one ring
+    a[2000] = a[1999]
+    b = b.copy()
+    b[0] = [np.nan, 1.0, 2.0]
+    b[1] = [np.inf, 0.0, 0.0]
+    b[2] = [-np.inf, np.inf, 0.0]
+    b[3] = [1e20, -1e20, 1e19]
+    b[4] = [0.0, 0.127, 0.0]                 # the scanner's centre: direction 0/0
+    b[5] = a[100]
+    b[6] = a[2000]
+    b[7] = [1e-30, 0.127, -1e-30]
+    with np.errstate(all="ignore"):
+        st, lines = _oracle_state(a, ORIGIN, "nns")
+        compute.prepareNNS(a, lines, b, ORIGIN)
+        for call in range(2):
+            idx, dist = compute.dispatchNNS(b)
+            ridx, rdist = st.dispatch_nns(b)
+            assert np.array_equal(idx, ridx), f"call {call}"
+            assert np.array_equal(bits(dist), bits(rdist)), f"call {call}"
+            assert np.array_equal(bits(compute.corr_out[:, 3]), bits(st.hint)), f"call {call}"
+        compute.prepareDispatchNormals(a, lines, ORIGIN)
+        ref_n = O.normals(O.pad_points(a), O.origin4(ORIGIN), O.pad_scan_lines(lines).astype(np.int64), 100)
+        assert np.array_equal(bits(compute.normals_out_a[:len(a)]), bits(ref_n))
+        for kind, prep, disp, rdisp in (("ls", compute.prepareLS, compute.dispatchLS, "dispatch_ls"),
+                                        ("plane", compute.preparePointPlane, compute.dispatchPointPlane, "dispatch_plane")):
+            sp, _ = _oracle_state(a, ORIGIN, kind)
+            prep(a, lines, b, ORIGIN)
+            H, bb = disp(b)
+            rH, rb = getattr(sp, rdisp)(b)
+            assert np.array_equal(bits(H), bits(rH)) and np.array_equal(bits(bb), bits(rb)), kind
+
+
+def test_device_loop_with_non_finite_source_points_matches_oracle(compute):
+    """The whole point-to-plane loop with NaN / infinite / far-away source points among the good ones: they
+    contribute nothing (nan0, the distance gate) and stay what they are under the float64 transform; every
+    iteration's H, b and dx equal the restatement's bit for bit."""
+    a, b = small_pair()
+    b = b.copy()
+    b[10] = [np.nan, np.nan, np.nan]
+    b[500] = [np.inf, 1.0, -np.inf]
+    b[900] = [4e18, 1.0, 2.0]
+    b[1300] = [0.0, 0.127, 0.0]
+    icp = PointcloudIcpContainer(compute)
+    with np.errstate(all="ignore"):
+        tr = []
+        O.full_pt2pl(a, b, ORIGIN, iterations=6, trace=tr)
+        icp.preparePointToPlane(a, ORIGIN, b)
+        dx, conv, hb, moved = compute.icpRun(b, MODE_PLANE, 6, want_hb=True, want_points=True)
+    assert len(dx) == len(tr) and len(tr) >= 2
+    for i, (H, bb, d) in enumerate(tr):
+        assert np.array_equal(bits(hb[i][:6, :6]), bits(H)), f"H at iteration {i}"
+        assert np.array_equal(bits(hb[i][:6, 6]), bits(bb)), f"b at iteration {i}"
+        assert np.array_equal(bits(dx[i]), bits(d)), f"dx at iteration {i}"
+    assert np.isnan(moved[10]).all() and np.isfinite(moved[11]).all()
