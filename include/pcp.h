@@ -149,6 +149,11 @@ int pcp_voxel_data_read(pcp_ctx* ctx, int rows, int max_points, int32_t* out);
 int pcp_voxelize(pcp_ctx* ctx, const float* pts_xyzw, int n, float voxel_size, int stored,
                  int begin_index, int max_points, int32_t* unknown, int unknown_len,
                  float* debug);
+/* The same for points given as n x 3 float32 (x, y, z): what pad_points (:956-961) would append, a
+ * zero fourth component, is added on the device, so the caller needs no padded copy. */
+int pcp_voxelize_xyz(pcp_ctx* ctx, const float* pts_xyz, int n, float voxel_size, int stored,
+                     int begin_index, int max_points, int32_t* unknown, int unknown_len,
+                     float* debug);
 /* The host half of Voxelizer.storeUnknownPoints (Voxelizer.py:170-306) on the device, for the
  * unknown points of the LAST pcp_voxelize call (its points and unknown list are still resident):
  * one new voxel per distinct coordinate, in lexicographic order; data row stored + rank holds the

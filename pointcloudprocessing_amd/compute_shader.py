@@ -265,11 +265,18 @@ class ComputeShader:
                 new_rows = np.ascontiguousarray(voxel_data[prev_stored_voxels:stored_voxel_num], dtype=np.int32)
                 check(self._lib.pcp_voxel_data_upload_rows(self._ctx, i32p(new_rows), int(prev_stored_voxels),
                                                            len(new_rows), int(max_points_to_store)))
-        pts = self.pad_points(np_points)
         debug_data = np.zeros((n, 4), dtype=np.float32) if debug else None
-        check(self._lib.pcp_voxelize(self._ctx, f32p(pts), n, float(np.asarray(voxel_size).reshape(-1)[0]),
-                                     int(stored_voxel_num), int(begin_index), int(max_points_to_store),
-                                     i32p(unknown_points), unknown_len, f32p(debug_data)))
+        size = float(np.asarray(voxel_size).reshape(-1)[0])
+        np_points = np.asarray(np_points)
+        if np_points.dtype == np.float32 and np_points.ndim == 2 and np_points.shape[1] == 3 and np_points.flags.c_contiguous:
+            # already float32 (x, y, z): the zero fourth component of pad_points is added on the device
+            check(self._lib.pcp_voxelize_xyz(self._ctx, f32p(np_points), n, size, int(stored_voxel_num),
+                                             int(begin_index), int(max_points_to_store), i32p(unknown_points),
+                                             unknown_len, f32p(debug_data)))
+        else:
+            pts = self.pad_points(np_points)
+            check(self._lib.pcp_voxelize(self._ctx, f32p(pts), n, size, int(stored_voxel_num), int(begin_index),
+                                         int(max_points_to_store), i32p(unknown_points), unknown_len, f32p(debug_data)))
         return unknown_points, debug_data
 
     def prepareDispatchVoxelStager(self, voxel_index, stored_voxel_num, max_points, voxel_statistics,

@@ -83,6 +83,12 @@ __device__ int find_voxel(const int4* __restrict__ table, const int stored, cons
     return bin_search(table, 2, z, true, fy, ly);
 }
 
+// (x, y, z) records of 12 bytes -> the (x, y, z, 0) records the kernels read (pad_points, ComputeShader.py:956-961)
+__global__ void k_pad_xyz(const float* __restrict__ xyz, int n, float4* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = make_float4(xyz[3 * (size_t)i + 0], xyz[3 * (size_t)i + 1], xyz[3 * (size_t)i + 2], 0.0f);
+}
+
 // VoxelShader.glsl:100-146
 __global__ void __launch_bounds__(256)
 k_voxelize(const float4* __restrict__ pts, int n, const int4* __restrict__ table, int stored,
@@ -437,8 +443,21 @@ int pcp_voxel_data_read(pcp_ctx* c, int rows, int max_points, int32_t* out) {
     return 0;
 }
 
+static int voxelize_impl(pcp_ctx* c, const float* pts, int floats_per_point, int n, float voxel_size, int stored,
+                         int begin_index, int max_points, int32_t* unknown, int unknown_len, float* debug);
+
 int pcp_voxelize(pcp_ctx* c, const float* pts_xyzw, int n, float voxel_size, int stored, int begin_index,
                  int max_points, int32_t* unknown, int unknown_len, float* debug) {
+    return voxelize_impl(c, pts_xyzw, 4, n, voxel_size, stored, begin_index, max_points, unknown, unknown_len, debug);
+}
+
+int pcp_voxelize_xyz(pcp_ctx* c, const float* pts_xyz, int n, float voxel_size, int stored, int begin_index,
+                     int max_points, int32_t* unknown, int unknown_len, float* debug) {
+    return voxelize_impl(c, pts_xyz, 3, n, voxel_size, stored, begin_index, max_points, unknown, unknown_len, debug);
+}
+
+static int voxelize_impl(pcp_ctx* c, const float* pts_xyzw, int floats_per_point, int n, float voxel_size, int stored,
+                         int begin_index, int max_points, int32_t* unknown, int unknown_len, float* debug) {
     if (int e = use(c)) return e;
     pcp_voxel_state* v = c->vox;
     if (!pts_xyzw || !unknown) return pcp_fail("null argument");
@@ -456,7 +475,16 @@ int pcp_voxelize(pcp_ctx* c, const float* pts_xyzw, int n, float voxel_size, int
         v->pts_cap = cap;
     }
     PCP_CHECK(hipMemsetAsync(v->unknown, 0, sizeof(int), c->stream));
-    PCP_CHECK(hipMemcpyAsync(v->pts, pts_xyzw, (size_t)n * sizeof(float4), hipMemcpyHostToDevice, c->stream));
+    if (floats_per_point == 4) {
+        PCP_CHECK(hipMemcpyAsync(v->pts, pts_xyzw, (size_t)n * sizeof(float4), hipMemcpyHostToDevice, c->stream));
+    } else {
+        // the 12-byte records land in the debug buffer (n float4, overwritten by the kernel only after this
+        // expansion has read them: one stream) and are widened on the device
+        float* staging = reinterpret_cast<float*>(v->debug);
+        PCP_CHECK(hipMemcpyAsync(staging, pts_xyzw, (size_t)n * 3 * sizeof(float), hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(k_pad_xyz, dim3(cdiv(n, 256)), dim3(256), 0, c->stream, staging, n, v->pts);
+        PCP_CHECK(hipGetLastError());
+    }
     hipLaunchKernelGGL(k_voxelize, dim3(cdiv(n, 256)), dim3(256), 0, c->stream, v->pts, n, v->table, stored, v->data,
                        v->data_rows, max_points, begin_index, voxel_size, v->unknown, debug ? v->debug : nullptr);
     PCP_CHECK(hipGetLastError());

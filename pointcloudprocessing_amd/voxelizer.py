@@ -77,10 +77,11 @@ class Voxelizer:
 
     # ------------------------------------------------------------------ per-frame entry (:81-165)
     def addPoints(self, np_points, colors, printt=False):
-        self.handleAddingPoints(np_points.astype(np.float32), colors)
+        pts32 = np.ascontiguousarray(np.asarray(np_points)[:, :3], dtype=np.float32)   # one float32 copy serves both
+        self.handleAddingPoints(pts32, colors)
         begin = self.last_added_point - len(np_points)
         unknown_points, _ = self.compute.prepareDispatchVoxelizer(
-            np_points=np_points, voxel_index=self.voxel_index, voxel_data=self.voxel_data,
+            np_points=pts32, voxel_index=self.voxel_index, voxel_data=self.voxel_data,
             voxel_size=self.voxel_size, stored_voxel_num=self.stored_voxels, begin_index=begin,
             max_points_to_store=self.max_points, realloc_needed=self.realloc_needed,
             prev_stored_voxels=self.prev_stored_voxels, debug=False)
@@ -214,8 +215,6 @@ class Voxelizer:
     def handleAddingPoints(self, np_points, colors=None):
         """:398-425 -- the global point store the voxel rows index into."""
         n = len(np_points)
-        if colors is None:
-            colors = np.full((n, 3), 255)
         if self.added_points is None:
             self.added_points = np.empty((n * 2, 4), dtype=np.float32)
             self.added_colors = np.empty((n * 2, 3), dtype=np.float32)
@@ -230,7 +229,8 @@ class Voxelizer:
                 new[:used] = old[:used]
                 setattr(self, name, new)
         self.added_points[self.last_added_point:self.last_added_point + n, :3] = np_points[:, :3]
-        self.added_colors[self.last_added_point:self.last_added_point + n] = colors
+        # colors=None means white (np.full((n, 3), 255) in the reference), written without the temporary
+        self.added_colors[self.last_added_point:self.last_added_point + n] = 255.0 if colors is None else colors
         self.last_added_point += n
 
     # ------------------------------------------------------------------ table search on the host (:429-570)
