@@ -980,16 +980,20 @@ MapLsArgs map_args(pcp_grid* g, double radius, bool per_point) {
 }
 
 // Which search kernel: with few queries a launch is a handful of waves per SIMD walking dependent
-// look-ups, and 32 lanes per query win (12 M-point map, 122 k queries: 1.7 -> 0.65 ms); with many
-// queries the GPU is full either way and one lane per query does less redundant work (1 M queries:
-// 0.26 against 0.67 ms).  PCP_GRID_LANES=1 or =32 in the environment forces one of them.
+// look-ups, and 32 lanes per query win (12 M-point map, 122 k queries: 1.7 -> 0.65 ms).  With many
+// queries the GPU is full either way: one lane per query does less redundant work on sparse cells
+// (1 M uniform points, 4 per cell: 0.30 against 0.71 ms), 32 lanes share the scan of crowded ones
+// (828 k LiDAR points, 83 per cell: 2.49 against 1.28 ms); the two meet at about 8 points per cell.
+// PCP_GRID_LANES=1 or =32 in the environment forces one of them.
 constexpr size_t LANES32_MAX_QUERIES = 262144;
-bool lane_per_query(const size_t m) {
+constexpr size_t LANES32_MIN_PER_CELL = 8;
+bool lane_per_query(const pcp_grid* g) {
     static const int forced = [] {
         const char* e = getenv("PCP_GRID_LANES");
         return !e ? 0 : (e[0] == '1' && e[1] == 0 ? 1 : (e[0] == '3' && e[1] == '2' && e[2] == 0 ? 32 : 0));
     }();
-    return forced == 1 || (forced == 0 && m > LANES32_MAX_QUERIES);
+    if (forced) return forced == 1;
+    return g->m > LANES32_MAX_QUERIES && g->n < LANES32_MIN_PER_CELL * g->n_cells;
 }
 
 int launch_nn32(pcp_grid* g, double max_d2, bool in_loop) {
@@ -1010,7 +1014,7 @@ int launch_map_ls(pcp_grid* g, int mode, double radius, bool per_point) {
     if (mode != PCP_MODE_POINT && mode != PCP_MODE_PLANE) return pcp_fail("unknown mode %d", mode);
     if (mode == PCP_MODE_PLANE && !g->have_normals) return pcp_fail("plane mode needs map normals (pcp_grid_build)");
     if (!(radius > 0.0)) return pcp_fail("search radius must be positive");
-    if (!lane_per_query(g->m)) {
+    if (!lane_per_query(g)) {
         if (launch_nn32(g, radius * radius, true)) return 1;
         const unsigned nb = blocks_for(g->m, PCP_BLOCK);
         if (mode == PCP_MODE_POINT)
@@ -1402,7 +1406,7 @@ int pcp_grid_query_resident(pcp_grid* g, double max_dist, long long* idx, double
     PCP_CHECK(hipSetDevice(g->device));
     const double max_d2 = (max_dist > 0.0 && std::isfinite(max_dist)) ? max_dist * max_dist : INFINITY;
     PCP_CHECK(hipEventRecord(g->ev0, g->stream));
-    if (lane_per_query(g->m)) {
+    if (lane_per_query(g)) {
         hipLaunchKernelGGL(k_grid_nn, dim3(blocks_for(g->m, 256)), dim3(256), 0, g->stream, view_of(g), g->src, g->m, max_d2,
                            g->nn_d, g->nn_idx, g->nn_pos);
         PCP_CHECK(hipGetLastError());
@@ -1433,7 +1437,7 @@ int pcp_grid_kd_step(pcp_grid* g, double keep_fraction, double* mean_ref, double
     const size_t m = g->m;
     const unsigned long long taken = (unsigned long long)((double)m * keep_fraction);    // int(len * percent)
     if (taken == 0) return pcp_fail("keep_fraction selects no point");
-    if (lane_per_query(m)) {
+    if (lane_per_query(g)) {
         hipLaunchKernelGGL(k_grid_nn, dim3(blocks_for(m, 256)), dim3(256), 0, s, view_of(g), g->src, m, (double)INFINITY,
                            g->nn_d, g->nn_idx, g->nn_pos);
     } else if (launch_nn32(g, (double)INFINITY, false)) {
