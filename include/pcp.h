@@ -115,6 +115,10 @@ int pcp_icp_run(pcp_ctx* ctx, const double* b_xyz, int n_b, int mode, int max_it
 /* The same loop split for callers that keep data in device memory: upload
  * once, launch without host synchronisation, fetch the small result later. */
 int pcp_upload_source(pcp_ctx* ctx, const double* b_xyz, int n_b);
+/* The same for a cloud held as three separate coordinate arrays of n_b float64 each -- what a
+ * transposed (3, n_b) result such as (R @ points.T).T of LidarDataReader.py:66-67 is in memory: the
+ * rows are uploaded as they lie and interleaved on the device, no host copy into (n_b, 3) order. */
+int pcp_upload_source_soa(pcp_ctx* ctx, const double* x, const double* y, const double* z, int n_b);
 /* Same from a buffer already in device memory (device-to-device copy on the
  * context's stream). */
 int pcp_upload_source_dev(pcp_ctx* ctx, const double* b_xyz_dev, int n_b);

@@ -46,6 +46,7 @@ SIGNATURES = {
     "pcp_icp_run": (C.c_int, [_ctx, _f64p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int,
                               _f32p, _f32p, _i32p, _i32p, _f64p]),
     "pcp_upload_source": (C.c_int, [_ctx, _f64p, C.c_int]),
+    "pcp_upload_source_soa": (C.c_int, [_ctx, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     "pcp_upload_source_dev": (C.c_int, [_ctx, C.c_void_p, C.c_int]),
     "pcp_icp_launch": (C.c_int, [_ctx, C.c_int, C.c_int, C.c_float, C.c_int]),
     "pcp_icp_fetch": (C.c_int, [_ctx, _f32p, _f32p, _i32p, _i32p, _f64p]),

@@ -193,14 +193,26 @@ class ComputeShader:
         """One call for the whole iteration loop of full_pt2pt / full_pt2pl
         (PointcloudIcpContainer.py:84-94, :118-133) on the prepared target.
         Returns (dx_trace (iters, 6) f32, converged, hb_trace | None, moved points | None)."""
-        b = np.ascontiguousarray(np.asarray(points_b)[:, :3], dtype=np.float64)
-        n = len(b)
+        pts = np.asarray(points_b)
+        n = len(pts)
         dx = np.zeros((max(iterations, 1), 6), dtype=np.float32)
         hb = np.zeros((max(iterations, 1), 8, 8), dtype=np.float32) if want_hb else None
-        out = np.empty_like(b) if want_points else None
+        out = np.empty((n, 3), dtype=np.float64) if want_points else None
         iters, conv = C.c_int(0), C.c_int(0)
-        check(self._lib.pcp_icp_run(self._ctx, f64p(b), n, int(mode), int(iterations), float(tol), int(full_iter),
-                                    f32p(dx), f32p(hb), C.byref(iters), C.byref(conv), f64p(out)))
+        cols = pts[:, :3].T if pts.ndim == 2 else None
+        if cols is not None and pts.dtype == np.float64 and n > 1 and cols.flags.c_contiguous:
+            # a transposed result such as (R @ p.T).T (LidarDataReader.py:66-67): its three coordinate
+            # rows go up as they lie, the (n, 3) order is made on the device
+            row = cols.strides[0]
+            base = cols.ctypes.data
+            check(self._lib.pcp_upload_source_soa(self._ctx, base, base + row, base + 2 * row, n))
+            check(self._lib.pcp_reset_hints(self._ctx))
+            check(self._lib.pcp_icp_launch(self._ctx, int(mode), int(iterations), float(tol), int(full_iter)))
+            check(self._lib.pcp_icp_fetch(self._ctx, f32p(dx), f32p(hb), C.byref(iters), C.byref(conv), f64p(out)))
+        else:
+            b = np.ascontiguousarray(pts[:, :3], dtype=np.float64)
+            check(self._lib.pcp_icp_run(self._ctx, f64p(b), n, int(mode), int(iterations), float(tol), int(full_iter),
+                                        f32p(dx), f32p(hb), C.byref(iters), C.byref(conv), f64p(out)))
         self._n_source = n
         k = iters.value
         return dx[:k], bool(conv.value), (hb[:k] if want_hb else None), out

@@ -408,6 +408,15 @@ __global__ void k_state_batch(const LsArgs* __restrict__ all, int n, int reset) 
     }
 }
 
+// rows x[n], y[n], z[n] -> points (x, y, z)[n]
+__global__ void k_interleave_xyz(const double* __restrict__ rows, int n, double* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    out[3 * (size_t)i + 0] = rows[i];
+    out[3 * (size_t)i + 1] = rows[(size_t)n + i];
+    out[3 * (size_t)i + 2] = rows[2 * (size_t)n + i];
+}
+
 // Applies the step still pending after the last dispatch.
 __global__ void k_apply_pending(double* __restrict__ b64, int n_b, IcpState* __restrict__ st) {
     if (!st->pending) return;
@@ -798,6 +807,22 @@ int pcp_upload_source(pcp_ctx* c, const double* b_xyz, int n_b) {
     if (n_b < 1 || n_b > c->max_points) return pcp_fail("n_b = %d outside [1, %d]", n_b, c->max_points);
     c->n_b = n_b;
     PCP_CHECK(hipMemcpyAsync(c->b_in, b_xyz, (size_t)n_b * 3 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    return 0;
+}
+
+int pcp_upload_source_soa(pcp_ctx* c, const double* x, const double* y, const double* z, int n_b) {
+    if (int e = use(c)) return e;
+    if (!x || !y || !z) return pcp_fail("null source points");
+    if (n_b < 1 || n_b > c->max_points) return pcp_fail("n_b = %d outside [1, %d]", n_b, c->max_points);
+    c->n_b = n_b;
+    // the three rows land in the working copy (rewritten by the loop's first iteration anyway) and are
+    // interleaved from there
+    const size_t row = (size_t)n_b * sizeof(double);
+    PCP_CHECK(hipMemcpyAsync(c->b64, x, row, hipMemcpyHostToDevice, c->stream));
+    PCP_CHECK(hipMemcpyAsync(c->b64 + n_b, y, row, hipMemcpyHostToDevice, c->stream));
+    PCP_CHECK(hipMemcpyAsync(c->b64 + 2 * (size_t)n_b, z, row, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_interleave_xyz, dim3(cdiv(n_b, 256)), dim3(256), 0, c->stream, c->b64, n_b, c->b_in);
+    PCP_CHECK(hipGetLastError());
     return 0;
 }
 

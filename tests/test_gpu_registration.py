@@ -491,3 +491,21 @@ def test_device_loop_with_non_finite_source_points_matches_oracle(compute):
         assert np.array_equal(bits(hb[i][:6, 6]), bits(bb)), f"b at iteration {i}"
         assert np.array_equal(bits(dx[i]), bits(d)), f"dx at iteration {i}"
     assert np.isnan(moved[10]).all() and np.isfinite(moved[11]).all()
+
+
+def test_transposed_source_arrays_take_the_row_upload_and_change_nothing(compute):
+    """A source cloud that is a transposed (3, N) array in memory -- what (R @ p.T).T leaves -- goes up as three
+    coordinate rows (pcp_upload_source_soa); steps, tiles and moved points equal those of the (N, 3) copy."""
+    a, b = small_pair()
+    bt = np.asfortranarray(b)                     # same values, column-major
+    assert bt[:, :3].T.flags.c_contiguous and not bt.flags.c_contiguous
+    wide = np.asfortranarray(np.hstack([b, np.ones((len(b), 1))]))      # (N, 4), fourth column ignored
+    icp = PointcloudIcpContainer(compute)
+    icp.preparePointToPlane(a, ORIGIN, b)
+    ref = compute.icpRun(np.ascontiguousarray(b), MODE_PLANE, 6, want_hb=True, want_points=True)
+    for arr in (bt, wide):
+        icp.preparePointToPlane(a, ORIGIN, b)
+        got = compute.icpRun(arr, MODE_PLANE, 6, want_hb=True, want_points=True)
+        assert np.array_equal(bits(got[0]), bits(ref[0])) and got[1] == ref[1]
+        assert np.array_equal(bits(got[2]), bits(ref[2]))
+        assert np.array_equal(got[3].view(np.uint64), ref[3].view(np.uint64))
