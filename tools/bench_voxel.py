@@ -31,6 +31,8 @@ for m in ("prepareDispatchVoxelizer", "prepareDispatchVoxelStager", "insertUnkno
 for rep in range(2):
     v = Voxelizer(cs, None)
     v.init(0.5)
+    for m in ("handleAddingPoints", "storeUnknownPoints"):
+        timed(v, m)
     for k, f in enumerate(frames * 2):
         t0 = time.perf_counter()
         v.addPoints(f, None)
