@@ -203,6 +203,94 @@ class PointcloudIcpContainer:
         delta_x = np.linalg.solve(H, -b)
         return delta_x[:3], delta_x[3:]
 
+    # ------------------------------------------------------------------ one point at a time (:207-314)
+    # The scalar statement of what LeastSquaresPoint.glsl computes per point (getH / getB, :20-43 there):
+    # float64, explicit sums, kept for checking the vectorised and the device versions against.
+    def getJ_i(self, point):
+        """:289-299 -- rows (1,0,0,0,-z,y), (0,1,0,z,0,-x), (0,0,1,-y,x,0)."""
+        x, y, z = float(point[0]), float(point[1]), float(point[2])
+        return np.array([[1.0, 0.0, 0.0, 0.0, -z, y],
+                         [0.0, 1.0, 0.0, z, 0.0, -x],
+                         [0.0, 0.0, 1.0, -y, x, 0.0]])
+
+    def getH_i(self, J_i):
+        """:254-265 -- H[i][j] = sum over the three rows k of J[k][i] * J[k][j], in that order."""
+        H_i = np.zeros((6, 6))
+        for i in range(6):
+            for j in range(6):
+                acc = 0.0
+                for k in range(3):
+                    acc += J_i[k][i] * J_i[k][j]
+                H_i[i][j] = acc
+        return H_i
+
+    def getH_i_vector(self, J_i):
+        """:251-252"""
+        return J_i.T @ J_i
+
+    def getB(self, J_i, e_i):
+        """:301-314 -- b[i] = sum over k of J[k][i] * e[k]."""
+        b_i = np.zeros(6)
+        for i in range(6):
+            acc = 0.0
+            for k in range(3):
+                acc += J_i[k][i] * e_i[k]
+            b_i[i] = acc
+        return b_i
+
+    def addH(self, H, H_i):
+        """:236-242"""
+        return np.array([[H[i][j] + H_i[i][j] for j in range(6)] for i in range(6)], dtype=np.float64)
+
+    def addB(self, B, b_i):
+        """:244-249"""
+        return np.array([B[i] + b_i[i] for i in range(6)], dtype=np.float64)
+
+    def getHsBsLoop(self, aligned, to_align):
+        """:207-221 -- per point i: e = aligned[i] - to_align[i], J of to_align[i], H_i and b_i."""
+        Hs, Bs = [], []
+        for p_a, p_b in zip(aligned[:len(to_align)], to_align):
+            J_i = self.getJ_i(p_b)
+            Hs.append(self.getH_i(J_i))
+            Bs.append(self.getB(J_i, p_a - p_b))
+        return np.array(Hs), np.array(Bs)
+
+    def sumHsBsLoop(self, Hs, Bs):
+        """:223-231 -- running sums in point order."""
+        H, b = np.zeros((6, 6)), np.zeros(6)
+        for H_i, b_i in zip(Hs, Bs):
+            H, b = self.addH(H, H_i), self.addB(b, b_i)
+        return H, b
+
+    # ------------------------------------------------------------------ geometry helpers of the reference's demos
+    def dist(self, p1, p2):
+        """:396-397"""
+        return np.linalg.norm(p1 - p2)
+
+    def getUniformGridSurface(self, pointsPerAxis):
+        """:440-453 -- the points of getUniformGrid that lie on the cube's faces."""
+        g = self.getUniformGrid(pointsPerAxis)
+        return g[np.any(np.abs(g) == 1.0, axis=1)]
+
+    def get_plane_grid(self, points_per_axis, y_value=0, gridsize=10.0):
+        """:524-535 -- a square grid in the plane y = y_value."""
+        axis = np.linspace(-1, 1, points_per_axis) * gridsize
+        X, Z = np.meshgrid(axis, axis, indexing="ij")
+        return np.vstack([X.ravel(), np.full(X.size, y_value, dtype=X.dtype), Z.ravel()]).T
+
+    def connectPointsInOrder(self, np_points):
+        """:517-522 -- line segments (p0, p1), (p1, p2), ... as consecutive row pairs."""
+        out = np.empty((2 * (len(np_points) - 1), 3), dtype=np_points.dtype)
+        out[0::2], out[1::2] = np_points[:-1], np_points[1:]
+        return out
+
+    def zipPointsToLines(self, points1, points2):
+        """:325-330 -- segments (points1[i], points2[i]); like the reference, the last common pair is left out."""
+        n = min(len(points1), len(points2)) - 1
+        out = np.empty((2 * n, 3), dtype=points1.dtype)
+        out[0::2], out[1::2] = points1[:n], points2[:n]
+        return out
+
     # ------------------------------------------------------------------ legacy exact-NN ICP (:465-515)
     def getKDTree(self, np_points, cell=None):
         """:471-472.  The tree is a device cell grid answering the same query()."""

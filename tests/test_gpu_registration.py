@@ -509,3 +509,32 @@ def test_transposed_source_arrays_take_the_row_upload_and_change_nothing(compute
         assert np.array_equal(bits(got[0]), bits(ref[0])) and got[1] == ref[1]
         assert np.array_equal(bits(got[2]), bits(ref[2]))
         assert np.array_equal(got[3].view(np.uint64), ref[3].view(np.uint64))
+
+
+def test_device_tiles_equal_the_scalar_loop_per_point(compute):
+    """Identity-correspondence mode (debug_info.x >= 1): every 8 x 8 tile of the point kernel against the
+    reference's scalar statement of it, getH_i / getB of to_align[i] and aligned[i] - to_align[i], evaluated in
+    float32 like the shader (bit-equal) and in float64 (1e-3, the bar of tests/GpuTest.py:561-582)."""
+    icp = PointcloudIcpContainer(compute)
+    a = icp.getUniformShape().astype(np.float32).astype(np.float64)
+    b = a + np.random.default_rng(2).normal(0, 0.05, a.shape).astype(np.float32)
+    b = b.astype(np.float32).astype(np.float64)
+    compute.prepareLS(a, [(0, len(a) - 1)], b, ORIGIN, debug_mode=True)     # rings play no part in this mode
+    tiles = compute.lsTiles(b, MODE_POINT, debug=True)
+    Hs, Bs = icp.getHsBsLoop(a[:300], b[:300])
+    assert np.allclose(tiles[:300, :6, :6], Hs, atol=1e-3) and np.allclose(tiles[:300, :6, 6], Bs, atol=1e-3)
+    f = np.float32
+    for i in (0, 17, 299):
+        J = icp.getJ_i(b[i]).astype(f)
+        e = (a[i].astype(f) - b[i].astype(f)).astype(f)
+        H32 = np.zeros((6, 6), f)
+        b32 = np.zeros(6, f)
+        for r in range(6):
+            for c in range(6):
+                acc = f(J[0][r] * J[0][c])
+                acc = f(acc + f(J[1][r] * J[1][c]))
+                H32[r][c] = f(acc + f(J[2][r] * J[2][c]))
+            acc = f(J[0][r] * e[0])
+            acc = f(acc + f(J[1][r] * e[1]))
+            b32[r] = f(acc + f(J[2][r] * e[2]))
+        assert np.array_equal(bits(tiles[i, :6, :6]), bits(H32)) and np.array_equal(bits(tiles[i, :6, 6]), bits(b32)), i

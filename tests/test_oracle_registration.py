@@ -206,3 +206,33 @@ def test_kd_alignment_restatement_equals_reference():
     moved, R_opt, t_opt = NG.align_kd(a, b)
     assert np.abs(R_opt - g["align_R"]).max() < 1e-7 and np.abs(t_opt - g["align_t"]).max() < 1e-6
     assert np.abs(moved[::64] - g["align_moved_sub"]).max() < 1e-5
+
+
+# ------------------------------------------------------------------------------ the reference's scalar KATs
+def test_unrolled_H_and_b_equal_the_matrix_products():
+    """tests/GpuTest.py:521-544 (test_H_unrollEqualsNumpyBehaviour, test_B_unrollEqualsNumpyBehaviour), same
+    point, same error vector, same 1e-3 bar."""
+    icp = PointcloudIcpContainer(None)
+    point = np.array([12.23, -12.82, 0.001])
+    error = np.array([1234.123, 12, -0.001])
+    j = icp.getJ_i(point)
+    assert np.allclose(j.T @ j, icp.getH_i(j), atol=1e-3)
+    assert np.array_equal(icp.getH_i_vector(j), j.T @ j)
+    assert np.allclose(j.T @ error, icp.getB(j, error), atol=1e-3)
+
+
+def test_uniform_grid_loop_equals_numpy():
+    """tests/GpuTest.py:546-559 (test_uniformGridNumpyEqualLoop): the per-point loop and the vectorised
+    getHsBsNumpy on a rotated, shifted 10 x 10 x 10 grid, 1e-3; and the running sums against np.sum."""
+    import random
+    random.seed(3)
+    icp = PointcloudIcpContainer(None)
+    grid1 = icp.getUniformGrid(10)
+    R = PointcloudAlignment.randomRotation(0.4)
+    t = PointcloudAlignment.randomTranslation1() * 10
+    grid2 = (R @ icp.getUniformGrid(10).T).T + t
+    Hs_loop, Bs_loop = icp.getHsBsLoop(grid1, grid2)
+    Hs_numpy, Bs_numpy = icp.getHsBsNumpy(grid1, grid2)
+    assert np.allclose(Hs_loop, Hs_numpy, atol=1e-3) and np.allclose(Bs_loop, Bs_numpy, atol=1e-3)
+    H, b = icp.sumHsBsLoop(Hs_loop[:100], Bs_loop[:100])
+    assert np.allclose(H, Hs_loop[:100].sum(axis=0), atol=1e-9) and np.allclose(b, Bs_loop[:100].sum(axis=0), atol=1e-9)
