@@ -257,6 +257,18 @@ int pcp_grid_info(pcp_grid* grid, unsigned long long* n_points, unsigned long lo
                   int* sort_passes, float* build_ms, float* sort_ms);
 /* The map in its sorted order: original index and coordinates of every entry. */
 int pcp_grid_sorted_ids(pcp_grid* grid, long long* ids, double* xyz);
+/* Normals for a map without scan rings.  The reference computes normals only along scan lines
+ * (NormalShader.glsl:73-101), which a PLY cloud such as the ones align_KD (:500-515) registers does
+ * not have; here the normal of a map point is the direction of least spread (smallest eigenvector of
+ * the float64 scatter matrix) of the map points strictly within `radius` of it, itself included.
+ * Points with fewer than max(min_points, 3) such points get a zero normal.  With viewpoint3 the
+ * normal is turned towards that point (as normalTowardsOrigin, NormalShader.glsl:62-71), without it
+ * its largest component is made positive.  radius may span at most 3 grid cells.  The normals stay
+ * resident for the plane mode of pcp_grid_ls*; normals_xyzw (rows of 4 float32, w = 0) and counts
+ * (points within the radius) receive them in the order of pcp_grid_sorted_ids; either may be NULL.
+ * No counterpart in the reference. */
+int pcp_grid_estimate_normals(pcp_grid* grid, double radius, int min_points, const double* viewpoint3,
+                              float* normals_xyzw, unsigned* counts);
 /* Upload m source points as the resident working copy (and a pristine copy that
  * pcp_grid_source_rewind restores). */
 int pcp_grid_source(pcp_grid* grid, const double* xyz, size_t m);

@@ -110,3 +110,39 @@ def map_ls_tile(target, normals, query, mode, radius, owned=None):
         tiles = O.ls_plane_tiles(a4, pb, n4, safe, d)
     tiles[~hit] = 0
     return O.hb_tree_sum(tiles), hit, idx
+
+
+def pca_normals(points, radius, min_points=3, viewpoint=None, only=None):
+    """Normals of a ring-less cloud as the product defines them (no counterpart in the reference, whose
+    NormalShader.glsl needs scan rings): smallest eigenvector (numpy.linalg.eigh) of the scatter matrix of
+    the points with ((dx^2 + dy^2) + dz^2) < radius^2 around each point, itself included; turned towards
+    `viewpoint` like normalTowardsOrigin (NormalShader.glsl:62-71), else largest component positive; zero
+    for fewer than max(min_points, 3) points.  Returns (normals float64 (n,3), counts, gap) where gap =
+    (second smallest - smallest eigenvalue) / largest says how well defined the direction is.
+    `only` = indices of the points to evaluate (rows of the others stay zero)."""
+    p = np.asarray(points, dtype=np.float64)
+    tree = KDTree(p)
+    rows = np.arange(len(p)) if only is None else np.asarray(only, dtype=np.int64)
+    near = tree.query_ball_point(p[rows], radius * (1.0 + 1e-9))
+    normals = np.zeros((len(p), 3))
+    counts = np.zeros(len(p), dtype=np.int64)
+    gap = np.zeros(len(p))
+    r2 = radius * radius
+    for i, cand in zip(rows, near):
+        d = p[np.asarray(cand, dtype=np.int64)] - p[i]
+        d2 = (d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2]
+        d = d[d2 < r2]
+        counts[i] = len(d)
+        if len(d) < max(min_points, 3):
+            continue
+        s1 = d.sum(axis=0)
+        C = d.T @ d - np.outer(s1, s1) / len(d)
+        w, V = np.linalg.eigh(C)
+        n = V[:, 0]
+        if viewpoint is not None:
+            flip = np.dot(np.asarray(viewpoint, dtype=np.float64) - p[i], n) < 0.0
+        else:
+            flip = n[int(np.argmax(np.abs(n)))] < 0.0
+        normals[i] = -n if flip else n
+        gap[i] = (w[1] - w[0]) / w[2] if w[2] > 0 else 0.0
+    return normals, counts, gap

@@ -67,6 +67,7 @@ SIGNATURES = {
     "pcp_grid_build_slab": (C.c_int, [C.c_void_p, _f64p, C.c_size_t, C.c_double, _f32p, C.c_double, C.c_ulonglong, C.c_ulonglong, C.POINTER(C.c_size_t)]),
     "pcp_grid_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong), _i32p, _i32p, _f32p, _f32p]),
     "pcp_grid_sorted_ids": (C.c_int, [C.c_void_p, C.POINTER(C.c_longlong), _f64p]),
+    "pcp_grid_estimate_normals": (C.c_int, [C.c_void_p, C.c_double, C.c_int, _f64p, _f32p, C.POINTER(C.c_uint)]),
     "pcp_grid_source": (C.c_int, [C.c_void_p, _f64p, C.c_size_t]),
     "pcp_grid_source_rewind": (C.c_int, [C.c_void_p]),
     "pcp_grid_source_read": (C.c_int, [C.c_void_p, _f64p]),

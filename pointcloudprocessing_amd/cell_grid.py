@@ -76,6 +76,26 @@ class CellGrid:
         check(self._lib.pcp_grid_sorted_ids(self._g, _i64p(ids), f64p(xyz)))
         return ids, xyz
 
+    def estimate_normals(self, radius, min_points=3, viewpoint=None, return_counts=False):
+        """Normals of the target itself for clouds without scan rings (the reference's NormalShader
+        needs ring neighbours): direction of least spread of the target points strictly within
+        `radius` of each point, turned towards `viewpoint` if given.  Returns (n, 4) float32 rows in
+        the order of the points given to the constructor (zero rows for points with fewer than
+        min_points neighbours, or not held by this slab); they stay on the device for MODE_PLANE."""
+        nrm = np.zeros((self.held, 4), dtype=np.float32)
+        cnt = np.zeros(self.held, dtype=np.uint32)
+        vp = None if viewpoint is None else np.ascontiguousarray(np.asarray(viewpoint, dtype=np.float64)[:3])
+        check(self._lib.pcp_grid_estimate_normals(self._g, float(radius), int(min_points), f64p(vp), f32p(nrm),
+                                                  cnt.ctypes.data_as(C.POINTER(C.c_uint))))
+        ids, _ = self.sorted_points()
+        out = np.zeros((self.n, 4), dtype=np.float32)
+        out[ids] = nrm
+        if not return_counts:
+            return out
+        counts = np.zeros(self.n, dtype=np.uint32)
+        counts[ids] = cnt
+        return out, counts
+
     # -- source cloud ---------------------------------------------------------------------
     def set_source(self, np_points):
         src = np.ascontiguousarray(np.asarray(np_points, dtype=np.float64)[:, :3])

@@ -663,6 +663,123 @@ __global__ void k_src_apply(double* __restrict__ src, size_t m, const double* __
 }
 
 // ------------------------------------------------------------------------------------------
+// Normals of a map that has no scan rings (a PLY cloud, an accumulated map): the reference's
+// NormalShader.glsl needs ring neighbours, so for such clouds the normal of a map point is the
+// direction of least spread of the map points strictly within `radius` of it (the point itself
+// included): smallest eigenvector of their scatter matrix, float64, turned towards a viewpoint like
+// normalTowardsOrigin (NormalShader.glsl:62-71) when one is given.  A half-wave serves one map point:
+// its lanes look up the cells the ball can touch (32 per round), the points of the cells found are
+// read 32 at a time, ten sums per lane meet in a butterfly.
+// ------------------------------------------------------------------------------------------
+
+struct PcaArgs {
+    GridView G;
+    double radius2;
+    int reach;                 // cells to either side of the own cell that the ball can touch
+    int min_points;
+    int towards;
+    double vx, vy, vz;
+    float4* normals;           // in the map's sorted order
+    unsigned* counts;          // points within the radius, or null
+};
+
+// One Jacobi rotation of the symmetric 3x3 matrix in the (p, q) plane; r is the third index.
+__device__ __forceinline__ void jacobi_rotate(double& app, double& aqq, double& apq, double& arp, double& arq,
+                                              double (&vp)[3], double (&vq)[3]) {
+    if (apq == 0.0) return;
+    const double theta = (aqq - app) / (2.0 * apq);
+    const double t = copysign(1.0, theta) / (fabs(theta) + sqrt(theta * theta + 1.0));
+    const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+    app -= t * apq;
+    aqq += t * apq;
+    apq = 0.0;
+    const double rp = c * arp - s * arq, rq = s * arp + c * arq;
+    arp = rp;
+    arq = rq;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const double a = c * vp[k] - s * vq[k], b = s * vp[k] + c * vq[k];
+        vp[k] = a;
+        vq[k] = b;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_grid_pca(const PcaArgs A) {
+    const GridView& G = A.G;
+    const int lane = threadIdx.x & 31;
+    const size_t j = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 5;       // one map point per half-wave
+    if (j >= G.n) return;
+    const GridPoint q = G.pts[j];
+    const int cx = cell_of(q.x, G.cell) - G.cminx, cy = cell_of(q.y, G.cell) - G.cminy, cz = cell_of(q.z, G.cell) - G.cminz;
+    const int w = 2 * A.reach + 1, ncell = w * w * w;
+    double s[10];
+#pragma unroll
+    for (int k = 0; k < 10; ++k) s[k] = 0.0;
+    for (int base = 0; base < ncell; base += 32) {
+        const int ci = base + lane;
+        unsigned start = 0, count = 0;
+        if (ci < ncell) {
+            const int x = cx + ci % w - A.reach, y = cy + (ci / w) % w - A.reach, z = cz + ci / (w * w) - A.reach;
+            if (x >= 0 && x < G.ex && y >= 0 && y < G.ey && z >= 0 && z < G.ez) {
+                const double gx = axis_gap(q.x, (double)(x + G.cminx) * G.cell, (double)(x + G.cminx + 1) * G.cell, G.eps);
+                const double gy = axis_gap(q.y, (double)(y + G.cminy) * G.cell, (double)(y + G.cminy + 1) * G.cell, G.eps);
+                const double gz = axis_gap(q.z, (double)(z + G.cminz) * G.cell, (double)(z + G.cminz + 1) * G.cell, G.eps);
+                if ((gx * gx + gy * gy) + gz * gz < A.radius2)
+                    if (!find_cell(G.table, G.log_cap, morton3((unsigned)x, (unsigned)y, (unsigned)z), start, count)) count = 0;
+            }
+        }
+        const int in_round = min(32, ncell - base);
+        for (int c = 0; c < in_round; ++c) {
+            const unsigned cs = __shfl(start, c, 32), cn = __shfl(count, c, 32);
+            for (unsigned jj = cs + lane; jj < cs + cn; jj += 32) {
+                const GridPoint p = G.pts[jj];
+                const double dx = p.x - q.x, dy = p.y - q.y, dz = p.z - q.z;
+                if ((dx * dx + dy * dy) + dz * dz < A.radius2) {
+                    s[0] += 1.0;
+                    s[1] += dx; s[2] += dy; s[3] += dz;
+                    s[4] += dx * dx; s[5] += dx * dy; s[6] += dx * dz;
+                    s[7] += dy * dy; s[8] += dy * dz; s[9] += dz * dz;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int sft = 16; sft > 0; sft >>= 1) {
+#pragma unroll
+        for (int k = 0; k < 10; ++k) s[k] += __shfl_xor(s[k], sft, 32);
+    }
+    if (lane != 0) return;
+    if (A.counts) A.counts[j] = (unsigned)s[0];
+    float4 out = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (s[0] >= (double)A.min_points) {
+        const double inv = 1.0 / s[0];
+        double a00 = s[4] - s[1] * s[1] * inv, a01 = s[5] - s[1] * s[2] * inv, a02 = s[6] - s[1] * s[3] * inv;
+        double a11 = s[7] - s[2] * s[2] * inv, a12 = s[8] - s[2] * s[3] * inv, a22 = s[9] - s[3] * s[3] * inv;
+        double v0[3] = {1.0, 0.0, 0.0}, v1[3] = {0.0, 1.0, 0.0}, v2[3] = {0.0, 0.0, 1.0};
+        for (int sweep = 0; sweep < 12; ++sweep) {
+            if (a01 == 0.0 && a02 == 0.0 && a12 == 0.0) break;
+            jacobi_rotate(a00, a11, a01, a02, a12, v0, v1);
+            jacobi_rotate(a00, a22, a02, a01, a12, v0, v2);
+            jacobi_rotate(a11, a22, a12, a01, a02, v1, v2);
+        }
+        double nx = v0[0], ny = v0[1], nz = v0[2], lam = a00;
+        if (a11 < lam) { nx = v1[0]; ny = v1[1]; nz = v1[2]; lam = a11; }
+        if (a22 < lam) { nx = v2[0]; ny = v2[1]; nz = v2[2]; lam = a22; }
+        const double len = sqrt((nx * nx + ny * ny) + nz * nz);
+        nx /= len; ny /= len; nz /= len;
+        bool flip;
+        if (A.towards) flip = ((A.vx - q.x) * nx + (A.vy - q.y) * ny) + (A.vz - q.z) * nz < 0.0;
+        else {                     // no viewpoint: the largest component is made positive
+            const double ax = fabs(nx), ay = fabs(ny), az = fabs(nz);
+            flip = (ax >= ay && ax >= az) ? nx < 0.0 : ((ay >= az) ? ny < 0.0 : nz < 0.0);
+        }
+        if (flip) { nx = -nx; ny = -ny; nz = -nz; }
+        if (len > 0.0 && len == len) out = make_float4((float)nx, (float)ny, (float)nz, 0.0f);
+    }
+    A.normals[j] = out;
+}
+
+// ------------------------------------------------------------------------------------------
 // scan-to-map least squares: exact neighbour within the search radius, then the
 // tile arithmetic of LeastSquaresPoint.glsl / LeastSquaresPlane.glsl on the float32
 // casts, summed by the ParalellHBSum tree (one wave = one shader workgroup).
@@ -1346,6 +1463,38 @@ int pcp_grid_sorted_ids(pcp_grid* g, long long* ids, double* xyz) {
         if (ids) ids[i] = h[i].id;
         if (xyz) { xyz[3 * i] = h[i].x; xyz[3 * i + 1] = h[i].y; xyz[3 * i + 2] = h[i].z; }
     }
+    return 0;
+}
+
+int pcp_grid_estimate_normals(pcp_grid* g, double radius, int min_points, const double* viewpoint3, float* normals_xyzw,
+                              unsigned* counts) {
+    if (!g) return pcp_fail("null grid");
+    if (!(radius > 0.0) || !std::isfinite(radius)) return pcp_fail("radius must be positive and finite");
+    if (g->n == 0) return pcp_fail("the grid holds no map (pcp_grid_build)");
+    const double cells = std::ceil(radius / g->cell);
+    if (cells > 3.0)
+        return pcp_fail("radius %g spans more than 3 cells of edge %g: build the grid with larger cells", radius, g->cell);
+    PCP_CHECK(hipSetDevice(g->device));
+    if (!g->normals) PCP_CHECK(hipMalloc(&g->normals, g->n * 16));
+    unsigned* d_counts = nullptr;
+    if (counts) PCP_CHECK(hipMalloc(&d_counts, g->n * 4));
+    PcaArgs A;
+    A.G = view_of(g);
+    A.radius2 = radius * radius;
+    A.reach = (int)cells;
+    A.min_points = std::max(min_points, 3);
+    A.towards = viewpoint3 ? 1 : 0;
+    A.vx = viewpoint3 ? viewpoint3[0] : 0.0; A.vy = viewpoint3 ? viewpoint3[1] : 0.0; A.vz = viewpoint3 ? viewpoint3[2] : 0.0;
+    A.normals = g->normals;
+    A.counts = d_counts;
+    hipLaunchKernelGGL(k_grid_pca, dim3(blocks_for(g->n * 32, 256)), dim3(256), 0, g->stream, A);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(g->stream);
+    if (e == hipSuccess && normals_xyzw) e = hipMemcpy(normals_xyzw, g->normals, g->n * 16, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && counts) e = hipMemcpy(counts, d_counts, g->n * 4, hipMemcpyDeviceToHost);
+    if (d_counts) (void)hipFree(d_counts);
+    if (e != hipSuccess) return pcp_fail("estimating normals failed: %s", hipGetErrorString(e));
+    g->have_normals = true;
     return 0;
 }
 

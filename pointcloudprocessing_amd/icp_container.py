@@ -324,3 +324,23 @@ class PointcloudIcpContainer:
             tree.cleanup()
         R_opt, t_opt = self.uniform_optimal_icp(reference_grid, self.getUniformGrid(10))
         return moved, R_opt, t_opt
+
+    def align_ringless_pt2pl(self, reference_points, points_to_align, radius, iterations=20, viewpoint=None,
+                             normal_radius=None, cell=None, full_iter=False):
+        """full_pt2pl (:103-144) for clouds without scan rings (PLY models, accumulated maps), where
+        neither the ring search nor NormalShader.glsl applies: exact neighbours within `radius` on the cell
+        grid of align_KD, normals from the reference cloud itself (least spread of the points within
+        normal_radius, default = radius), the tiles and the sum of LeastSquaresPlane.glsl / ParalellHBSum.glsl,
+        the whole loop on the device.  Returns (moved points, t_opt, R_opt) with full_pt2pl's pose convention
+        (p <- R_opt p - t_opt).  No counterpart in the reference."""
+        normal_radius = float(radius if normal_radius is None else normal_radius)
+        tree = self.getKDTree(reference_points, cell=cell if cell is not None else max(float(radius), normal_radius))
+        try:
+            tree.estimate_normals(normal_radius, viewpoint=viewpoint)
+            tree.set_source(points_to_align)
+            dx, converged, _ = tree.icp_run(1, float(radius), max_iter=int(iterations), full_iter=full_iter)
+            moved = tree.read_source()
+        finally:
+            tree.cleanup()
+        t_opt, R_opt = self._replay(dx, len(dx) - (1 if converged else 0))
+        return moved, t_opt, R_opt

@@ -382,3 +382,96 @@ def test_device_partition_and_slab_equal_the_numpy_statement():
                 g.cleanup()
     with pytest.raises(RuntimeError):
         partition_keys(np.array([[0.0, 0, 0], [1e9, 0, 0]]), 0.5, 2)
+
+
+def _torus(n, seed, noise=0.002):
+    rng = np.random.default_rng(seed)
+    u, v = rng.uniform(0, 2 * np.pi, n), rng.uniform(0, 2 * np.pi, n)
+    R0, r0 = 1.0, 0.35
+    p = np.column_stack([(R0 + r0 * np.cos(v)) * np.cos(u), (R0 + r0 * np.cos(v)) * np.sin(u), r0 * np.sin(v)])
+    outward = np.column_stack([np.cos(v) * np.cos(u), np.cos(v) * np.sin(u), np.sin(v)])
+    return p + noise * rng.normal(size=p.shape), outward
+
+
+def _assert_normals_equal_checker(p, nrm, cnt, radius, viewpoint, only=None):
+    ref, ref_cnt, gap = NG.pca_normals(p, radius, viewpoint=viewpoint, only=only)
+    rows = np.arange(len(p)) if only is None else only
+    assert np.array_equal(cnt[rows], ref_cnt[rows])                       # the same ball of neighbours, exactly
+    none = rows[ref_cnt[rows] < 3]
+    assert not np.any(nrm[none])
+    good = rows[(ref_cnt[rows] >= 3) & (gap[rows] > 1e-3)]
+    assert len(good) > 0.8 * len(rows)
+    n = nrm[good, :3].astype(np.float64)
+    assert np.all(nrm[good, 3] == 0) and np.allclose(np.linalg.norm(n, axis=1), 1.0, atol=1e-6)
+    # float32 rows of a float64 eigenvector: same direction AND same sense as numpy's eigh (the sense
+    # may differ only where the normal is perpendicular to the line of sight / its largest components tie)
+    dots = np.einsum("ij,ij->i", n, ref[good])
+    assert np.all(np.abs(dots) > 1.0 - 1e-6)
+    if viewpoint is not None:
+        sight = np.abs(np.einsum("ij,ij->i", ref[good], np.asarray(viewpoint) - p[good]))
+        sure = sight > 1e-6
+    else:
+        a = np.sort(np.abs(ref[good]), axis=1)
+        sure = a[:, 2] - a[:, 1] > 1e-6
+    assert np.all(dots[sure] > 0)
+    return good
+
+
+@pytest.mark.parametrize("cell,viewpoint", [(0.08, None), (0.08, (0.0, 0.0, 5.0)), (0.03, (3.0, 1.0, 0.5))])
+def test_ringless_normals_equal_the_eigh_checker(cell, viewpoint):
+    """No counterpart in the reference (its normals need scan rings): parity unpinned, the checker is
+    numpy.linalg.eigh on the same ball of neighbours."""
+    p, outward = _torus(20000, 5)
+    p[:40] += 50.0 + 10.0 * np.arange(40)[:, None]                        # stray points: fewer than 3 in the ball
+    g = CellGrid(p, cell=cell)
+    try:
+        nrm, cnt = g.estimate_normals(0.08, viewpoint=viewpoint, return_counts=True)
+        good = _assert_normals_equal_checker(p, nrm, cnt, 0.08, viewpoint)
+        assert not np.any(nrm[:40]) and np.all(cnt[:40] == 1)
+        # and they are the surface's normals: within a few degrees of the torus' own
+        on = good[good >= 40]
+        assert np.median(np.abs(np.einsum("ij,ij->i", nrm[on, :3], outward[on]))) > 0.995
+        with pytest.raises(RuntimeError):
+            g.estimate_normals(cell * 3.5)                                 # ball wider than 3 cells
+    finally:
+        g.cleanup()
+
+
+def test_ringless_normals_on_a_kitti_frame(frames):
+    a = frames[0]
+    g = CellGrid(a, cell=0.25)
+    try:
+        nrm, cnt = g.estimate_normals(0.5, viewpoint=(0.0, 0.0, 0.0), return_counts=True)
+        only = np.arange(0, len(a), 23)
+        _assert_normals_equal_checker(a, nrm, cnt, 0.5, (0.0, 0.0, 0.0), only)
+    finally:
+        g.cleanup()
+
+
+def test_ringless_point_to_plane_registration_recovers_a_known_motion():
+    """A cloud without scan rings against its rigidly moved, noisy copy: normals from the cloud itself,
+    exact neighbours, the plane tiles of LeastSquaresPlane.glsl."""
+    a, _ = _torus(60000, 7, noise=0.001)
+    a = np.vstack([a, np.column_stack([np.random.default_rng(8).uniform(-2, 2, (20000, 2)), np.full(20000, -0.4)])])
+    R = lidar.rotation_xyz(0.02, -0.01, 0.015)
+    t = np.array([0.05, -0.02, 0.03])
+    rng = np.random.default_rng(9)
+    pick = rng.permutation(len(a))[:50000]
+    src = (R @ a[pick].T).T + t + rng.normal(0, 0.001, (len(pick), 3))
+    g = CellGrid(a, cell=0.06)
+    icp = PointcloudIcpContainer(None)
+    try:
+        g.estimate_normals(0.06, viewpoint=(0.0, 0.0, 10.0))
+        g.set_source(src)
+        dx, conv, hb = g.icp_run(1, 0.15, max_iter=30)
+        t_opt, R_opt = icp._replay(dx, len(dx) - (1 if conv else 0))
+        # moved = R_opt src - t_opt must undo src = R a + t
+        assert np.abs(R_opt @ R - np.eye(3)).max() < 1e-3 and np.abs(R_opt @ t - t_opt).max() < 2e-3
+        moved_loop = g.read_source()
+    finally:
+        g.cleanup()
+    # the container's driver is that loop
+    moved, t2, R2 = icp.align_ringless_pt2pl(a, src, 0.15, iterations=30, viewpoint=(0.0, 0.0, 10.0),
+                                             normal_radius=0.06, cell=0.06)
+    assert np.array_equal(moved, moved_loop) and np.array_equal(t2, t_opt) and np.array_equal(R2, R_opt)
+    assert np.abs(moved - a[pick]).max() < 0.01
