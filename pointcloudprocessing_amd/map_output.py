@@ -116,3 +116,58 @@ def read_ply_ascii(path):
     points[:] = data[:, :6]
     points[:, 3:] = points[:, 3:].clip(0, 255).astype(np.float32) / 255.0
     return points
+
+
+_PLY_TYPES = {"char": "i1", "int8": "i1", "uchar": "u1", "uint8": "u1", "short": "i2", "int16": "i2",
+              "ushort": "u2", "uint16": "u2", "int": "i4", "int32": "i4", "uint": "u4", "uint32": "u4",
+              "float": "f4", "float32": "f4", "double": "f8", "float64": "f8"}
+
+
+def read_ply_binary(path):
+    """PointcloudHandler.tryReadBinPly (:114-135) without the plyfile package: the first element of a
+    binary_little_endian / binary_big_endian PLY, (N, 6) float32 rows (x, y, z, r, g, b) with colours
+    scaled by 1/255 when the element has red/green/blue, zeros otherwise."""
+    with open(path, "rb") as f:
+        if f.readline().strip() != b"ply":
+            raise ValueError("not a PLY file: " + path)
+        order, count, fields, element = None, None, [], 0
+        while True:
+            line = f.readline()
+            if not line:
+                raise ValueError("PLY header without end_header")
+            words = line.decode("ascii").split()
+            if not words:
+                continue
+            if words[0] == "format":
+                if words[1] not in ("binary_little_endian", "binary_big_endian"):
+                    raise ValueError("not a binary PLY (format " + words[1] + ")")
+                order = "<" if words[1] == "binary_little_endian" else ">"
+            elif words[0] == "element":
+                element += 1
+                if element == 1:
+                    count = int(words[2])
+            elif words[0] == "property" and element == 1:
+                if words[1] == "list":
+                    raise ValueError("list properties in the first PLY element are not supported")
+                if len(words) < 3 or words[1] not in _PLY_TYPES:
+                    raise ValueError("malformed PLY property line: " + " ".join(words))
+                fields.append((words[2], _PLY_TYPES[words[1]]))
+            elif words[0] == "end_header":
+                break
+        if order is None or count is None:
+            raise ValueError("PLY header is missing its format or element line")
+        vertex = np.fromfile(f, dtype=np.dtype([(n, order + t) for n, t in fields]), count=count)
+    if len(vertex) != count:
+        raise ValueError("PLY file ends before its %d vertices" % count)
+    xyz = np.stack([vertex["x"], vertex["y"], vertex["z"]], axis=-1)
+    if "red" in vertex.dtype.names:
+        rgb = np.stack([vertex["red"], vertex["green"], vertex["blue"]], axis=-1).astype(np.float32) / 255.0
+    else:
+        rgb = np.zeros_like(xyz)
+    return np.hstack((xyz, rgb)).astype(np.float32)
+
+
+def load_pointcloud(path):
+    """PointcloudHandler.loadPointcloud (:152-166): a text PLY if the file reads as one, else a binary PLY."""
+    points = read_ply_ascii(path)
+    return points if points is not None else read_ply_binary(path)

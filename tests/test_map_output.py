@@ -80,3 +80,49 @@ def test_ply_text_format_and_round_trip(tmp_path):
     assert read_ply_ascii(empty).shape == (0, 6)
     (tmp_path / "bin.ply").write_bytes(b"ply\nformat binary_little_endian 1.0\n\xff\xfe\x00\x80")
     assert read_ply_ascii(str(tmp_path / "bin.ply")) is None
+
+
+@pytest.mark.parametrize("order,fmt", [("<", "binary_little_endian"), (">", "binary_big_endian")])
+def test_binary_ply_is_read_like_the_reference_reads_it(tmp_path, order, fmt):
+    """tryReadBinPly (PointcloudHandler.py:114-135) returns float32 (x, y, z, r/255, g/255, b/255), zeros
+    for colours the file does not have; the plyfile package it uses is not installed, so the file is
+    written here with numpy (parity of the reader unpinned beyond this statement of the format)."""
+    from pointcloudprocessing_amd.map_output import load_pointcloud, read_ply_binary
+    rng = np.random.default_rng(3)
+    n = 1000
+    v = np.zeros(n, dtype=[("x", order + "f4"), ("y", order + "f4"), ("z", order + "f4"), ("nx", order + "f8"),
+                           ("red", "u1"), ("green", "u1"), ("blue", "u1"), ("alpha", "u1")])
+    for k in ("x", "y", "z", "nx"):
+        v[k] = rng.normal(size=n)
+    for k in ("red", "green", "blue", "alpha"):
+        v[k] = rng.integers(0, 256, n)
+    header = ("ply\nformat %s 1.0\ncomment made by a test\nelement vertex %d\nproperty float x\nproperty float y\n"
+              "property float z\nproperty double nx\nproperty uchar red\nproperty uchar green\nproperty uchar blue\n"
+              "property uchar alpha\nelement face 0\nproperty list uchar int vertex_indices\nend_header\n" % (fmt, n))
+    path = str(tmp_path / "model.ply")
+    with open(path, "wb") as f:
+        f.write(header.encode("ascii"))
+        v.tofile(f)
+    got = read_ply_binary(path)
+    assert got.dtype == np.float32 and got.shape == (n, 6)
+    assert np.array_equal(got[:, 0], v["x"].astype(np.float32)) and np.array_equal(got[:, 2], v["z"].astype(np.float32))
+    assert np.array_equal(got[:, 3:], np.stack([v["red"], v["green"], v["blue"]], axis=-1).astype(np.float32) / 255.0)
+    loaded = load_pointcloud(path)                      # the text reader gives up on the bytes, the binary one takes over
+    assert loaded is not None and np.array_equal(loaded, got)
+    plain = np.zeros(5, dtype=[("x", order + "f8"), ("y", order + "f8"), ("z", order + "f8")])
+    plain["x"] = np.arange(5)
+    p2 = str(tmp_path / "plain.ply")
+    with open(p2, "wb") as f:
+        f.write(("ply\nformat %s 1.0\nelement vertex 5\nproperty double x\nproperty double y\nproperty double z\nend_header\n"
+                 % fmt).encode("ascii"))
+        plain.tofile(f)
+    got = read_ply_binary(p2)
+    assert np.array_equal(got[:, 0], np.arange(5, dtype=np.float32)) and not np.any(got[:, 1:])
+    import os
+    for cut in (os.path.getsize(p2) - 30, 70):           # inside the vertex data / inside the header
+        with open(p2, "r+b") as f:
+            f.truncate(cut)
+        with pytest.raises(ValueError):
+            read_ply_binary(p2)
+    text = save_ply(str(tmp_path / "text"), np.zeros((2, 6)))
+    assert load_pointcloud(text).shape == (2, 6)
