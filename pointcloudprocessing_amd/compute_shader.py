@@ -314,6 +314,11 @@ class ComputeShader:
 
     def getFullVoxelData(self, prev_stored_voxels, max_points, voxelizer_voxel_data):
         """:946-954 -- fills voxelizer_voxel_data[:prev_stored_voxels] in place."""
+        out = voxelizer_voxel_data
+        if (isinstance(out, np.ndarray) and out.dtype == np.int32 and out.flags.c_contiguous and out.ndim == 2
+                and out.shape[1] == int(max_points) and len(out) >= int(prev_stored_voxels)):
+            check(self._lib.pcp_voxel_data_read(self._ctx, int(prev_stored_voxels), int(max_points), i32p(out)))
+            return
         tmp = np.empty((int(prev_stored_voxels), int(max_points)), dtype=np.int32)
         check(self._lib.pcp_voxel_data_read(self._ctx, len(tmp), int(max_points), i32p(tmp)))
         voxelizer_voxel_data[:prev_stored_voxels] = tmp

@@ -7,10 +7,10 @@ The device appends the points of a new cloud to the voxels already in the table
 are created by the reference on the host, one at a time in a Python loop (an O(M)
 shift of the sorted table per voxel, :199-255) followed by a re-upload of table
 and rows; with this package's ComputeShader they are created on the device as well
-(insertUnknownVoxels) and only the table and the new rows' counts come back to the
-host arrays.  Table, data-row numbering, counts and id sets come out the same.
-The host arrays' point ids are then as stale as the reference's are for appended
-points: refreshVoxelData() (or any getter of stored ids) reads them back.
+(insertUnknownVoxels) and only the table comes back to the host per frame.  Table,
+data-row numbering, counts and id sets come out the same.  The host copy of the rows
+(voxel_data) is read back from the device when it is looked at (the attribute itself,
+refreshVoxelData() or any getter of stored ids), never per frame.
 When another compute object is injected (e.g. the reference's own), the batch
 merge below runs on the host instead.
 """
@@ -27,6 +27,7 @@ class Voxelizer:
         self.voxman = voxman              # render hand-off object with frameVoxelized(points, colors, separate)
 
         self.voxel_index = None           # (M, 4) int32: vx, vy, vz, data row; sorted; grows x2
+        self._rows_stale = False
         self.voxel_data = None            # (M, max_points) int32: [0] count, [1:] point ids
         self.voxel_stats = None           # (M, 4) float32, by data row
         self.stored_voxels = None
@@ -42,6 +43,29 @@ class Voxelizer:
         self.filter_outliers = None
         self.last_run_realloc = None
         self.inited = False
+
+    # The reference's host copy of the rows goes stale with every dispatch (the device appends to it) and
+    # is brought up to date by refreshVoxelData.  With the map kept on the device the host copy is not
+    # even written when voxels are created -- touching one count in every 4 KB row of a lazily zeroed
+    # array costs a page fault per voxel, more than the whole device side of a frame -- and is instead
+    # read back when somebody looks at it.
+    @property
+    def voxel_data(self):
+        if self._rows_stale and self._voxel_data is not None:
+            self._pull_rows()
+        return self._voxel_data
+
+    @voxel_data.setter
+    def voxel_data(self, value):
+        self._voxel_data = value
+        self._rows_stale = False
+
+    def _pull_rows(self):
+        rows = len(self.voxel_index)
+        if len(self._voxel_data) < rows:        # rows past stored_voxels are zero, on the device too
+            self._voxel_data = np.zeros((rows, self.max_points), dtype=np.int32)
+        self.compute.getFullVoxelData(self.stored_voxels, self.max_points, self._voxel_data)
+        self._rows_stale = False
 
     # ------------------------------------------------------------------ life cycle (:48-79, :382-388)
     def init(self, voxel_size):
@@ -81,10 +105,12 @@ class Voxelizer:
         self.handleAddingPoints(pts32, colors)
         begin = self.last_added_point - len(np_points)
         unknown_points, _ = self.compute.prepareDispatchVoxelizer(
-            np_points=pts32, voxel_index=self.voxel_index, voxel_data=self.voxel_data,
+            np_points=pts32, voxel_index=self.voxel_index, voxel_data=self._voxel_data,
             voxel_size=self.voxel_size, stored_voxel_num=self.stored_voxels, begin_index=begin,
             max_points_to_store=self.max_points, realloc_needed=self.realloc_needed,
             prev_stored_voxels=self.prev_stored_voxels, debug=False)
+        if hasattr(self.compute, "insertUnknownVoxels"):
+            self._rows_stale = True           # the device appended to its rows; the host copy is read back on demand
         self.voxel_stats, voxels_to_render = self.compute.prepareDispatchVoxelStager(
             self.voxel_index, self.stored_voxels, self.max_points, self.voxel_stats,
             filter_outliers=self.filter_outliers, stage_everything=False)
@@ -101,11 +127,10 @@ class Voxelizer:
 
     def refreshVoxelData(self):
         if not self.last_run_realloc:
-            self.compute.getFullVoxelData(self.stored_voxels, self.max_points, self.voxel_data)
-            self._rows_stale = False
+            self._pull_rows()
 
     def _fresh_rows(self):
-        if getattr(self, "_rows_stale", False):
+        if self._rows_stale:
             self.refreshVoxelData()
 
     def stageAllRemaningVoxels(self, ui=None):
@@ -147,12 +172,10 @@ class Voxelizer:
         # Rows past stored_voxels are zero, so only the used rows are carried over into a freshly
         # zeroed (lazily mapped) array; when the device holds the authoritative rows the host copy is
         # stale anyway and will be read back before anybody looks at it, so only the counts move.
-        old, used = self.voxel_data, self.stored_voxels
-        self.voxel_data = np.zeros((2 * len(old), old.shape[1]), dtype=old.dtype)
-        if getattr(self, "_rows_stale", False):
-            self.voxel_data[:used, 0] = old[:used, 0]
-        else:
-            self.voxel_data[:used] = old[:used]
+        if not self._rows_stale:             # a stale copy is re-made at full size when it is next read
+            old, used = self._voxel_data, self.stored_voxels
+            self._voxel_data = np.zeros((2 * len(old), old.shape[1]), dtype=old.dtype)
+            self._voxel_data[:used] = old[:used]
         fresh = np.zeros_like(self.voxel_stats)
         fresh[:, 0] = 0.5
         self.voxel_stats = np.vstack([self.voxel_stats, fresh])
@@ -168,12 +191,10 @@ class Voxelizer:
             return False, prev_stored
         if hasattr(self.compute, "insertUnknownVoxels"):
             new_stored, _ = self.compute.insertUnknownVoxels(self.max_points)
+            self._rows_stale = True
             while new_stored >= len(self.voxel_index):
                 self._grow()                       # host arrays only: the device grew its own
             self.compute.readVoxelIndex(new_stored, self.voxel_index)
-            self.voxel_data[prev_stored:new_stored, 0] = self.compute.readVoxelCounts(prev_stored,
-                                                                                      new_stored - prev_stored)
-            self._rows_stale = True
             self.stored_voxels = new_stored
             return False, prev_stored
         ids = np.sort(unknown_points[1:n + 1])     # the device appends in no particular order
