@@ -32,6 +32,7 @@ class Voxelizer:
         self.voxel_stats = None           # (M, 4) float32, by data row
         self.stored_voxels = None
 
+        self._pending = []                # clouds noted by handleAddingPoints, not yet in added_points
         self.added_points = None
         self.added_colors = None
         self.last_added_point = None
@@ -71,6 +72,7 @@ class Voxelizer:
     def init(self, voxel_size):
         self.inited = False
         self.last_added_point = 0
+        self._pending = []
         self.stored_voxels = 0
         self.realloc_needed = True
         self.prev_stored_voxels = -1
@@ -101,8 +103,8 @@ class Voxelizer:
 
     # ------------------------------------------------------------------ per-frame entry (:81-165)
     def addPoints(self, np_points, colors, printt=False):
-        pts32 = np.ascontiguousarray(np.asarray(np_points)[:, :3], dtype=np.float32)   # one float32 copy serves both
-        self.handleAddingPoints(pts32, colors)
+        self.handleAddingPoints(np_points, colors)
+        pts32 = self._pending[-1][1]                   # the float32 copy the point store keeps serves the dispatch too
         begin = self.last_added_point - len(np_points)
         unknown_points, _ = self.compute.prepareDispatchVoxelizer(
             np_points=pts32, voxel_index=self.voxel_index, voxel_data=self._voxel_data,
@@ -234,25 +236,58 @@ class Voxelizer:
         return was_realloc, prev_stored
 
     def handleAddingPoints(self, np_points, colors=None):
-        """:398-425 -- the global point store the voxel rows index into."""
+        """:398-425 -- the global point store the voxel rows index into.  A cloud is only noted here;
+        it is written into added_points / added_colors (float32 (cap, 4) / (cap, 3), capacity doubling
+        as in the reference) when one of the two is next looked at: the per-frame path never reads them."""
         n = len(np_points)
-        if self.added_points is None:
-            self.added_points = np.empty((n * 2, 4), dtype=np.float32)
-            self.added_colors = np.empty((n * 2, 3), dtype=np.float32)
-        if self.last_added_point + n >= len(self.added_points):
-            size = len(self.added_points)
-            while self.last_added_point + n >= size:       # doubling, as the reference does
+        pts = np.array(np.asarray(np_points)[:, :3], dtype=np.float32, order="C")   # the caller may reuse its array
+        cols = None if colors is None else np.array(colors, dtype=np.float32)
+        self._pending.append((self.last_added_point, pts, cols))
+        self.last_added_point += n
+
+    def _flush_points(self):
+        if not self._pending:
+            return
+        pending, self._pending = self._pending, []
+        need = self.last_added_point
+        if self._added_points is None:
+            first = len(pending[0][1])
+            self._added_points = np.empty((max(first * 2, 1), 4), dtype=np.float32)
+            self._added_colors = np.empty((max(first * 2, 1), 3), dtype=np.float32)
+        size = len(self._added_points)
+        if need >= size:
+            while need >= size:                            # doubling, as the reference does
                 size *= 2
-            used = self.last_added_point
-            for name in ("added_points", "added_colors"):  # only the rows in use are carried over
+            used = pending[0][0]
+            for name in ("_added_points", "_added_colors"):  # only the rows in use are carried over
                 old = getattr(self, name)
                 new = np.empty((size, old.shape[1]), dtype=old.dtype)
                 new[:used] = old[:used]
                 setattr(self, name, new)
-        self.added_points[self.last_added_point:self.last_added_point + n, :3] = np_points[:, :3]
-        # colors=None means white (np.full((n, 3), 255) in the reference), written without the temporary
-        self.added_colors[self.last_added_point:self.last_added_point + n] = 255.0 if colors is None else colors
-        self.last_added_point += n
+        for start, pts, cols in pending:
+            self._added_points[start:start + len(pts), :3] = pts
+            # colors=None means white (np.full((n, 3), 255) in the reference), written without the temporary
+            self._added_colors[start:start + len(pts)] = 255.0 if cols is None else cols
+
+    @property
+    def added_points(self):
+        self._flush_points()
+        return self._added_points
+
+    @added_points.setter
+    def added_points(self, value):
+        self._added_points = value
+        if value is None:
+            self._pending = []
+
+    @property
+    def added_colors(self):
+        self._flush_points()
+        return self._added_colors
+
+    @added_colors.setter
+    def added_colors(self, value):
+        self._added_colors = value
 
     # ------------------------------------------------------------------ table search on the host (:429-570)
     def xyzSortedArray(self, np_array):
