@@ -158,6 +158,12 @@ int pcp_voxelize(pcp_ctx* ctx, const float* pts_xyzw, int n, float voxel_size, i
 int pcp_voxelize_xyz(pcp_ctx* ctx, const float* pts_xyz, int n, float voxel_size, int stored,
                      int begin_index, int max_points, int32_t* unknown, int unknown_len,
                      float* debug);
+/* The same for a cloud held as three coordinate rows (xyz_rows = n x values, then n y, then n z, float32):
+ * what the float32 cast of a transposed cloud such as (R @ points.T).T of LidarDataReader.py:66-67 is in
+ * memory; the rows are interleaved on the device. */
+int pcp_voxelize_rows(pcp_ctx* ctx, const float* xyz_rows, int n, float voxel_size, int stored,
+                      int begin_index, int max_points, int32_t* unknown, int unknown_len,
+                      float* debug);
 /* The host half of Voxelizer.storeUnknownPoints (Voxelizer.py:170-306) on the device, for the
  * unknown points of the LAST pcp_voxelize call (its points and unknown list are still resident):
  * one new voxel per distinct coordinate, in lexicographic order; data row stored + rank holds the

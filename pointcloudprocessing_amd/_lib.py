@@ -57,6 +57,7 @@ SIGNATURES = {
     "pcp_voxel_data_read": (C.c_int, [_ctx, C.c_int, C.c_int, _i32p]),
     "pcp_voxelize": (C.c_int, [_ctx, _f32p, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, _i32p, C.c_int, _f32p]),
     "pcp_voxelize_xyz": (C.c_int, [_ctx, _f32p, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, _i32p, C.c_int, _f32p]),
+    "pcp_voxelize_rows": (C.c_int, [_ctx, _f32p, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, _i32p, C.c_int, _f32p]),
     "pcp_voxel_stage": (C.c_int, [_ctx, _f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _i32p, _i32p]),
     "pcp_grid_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
     "pcp_grid_destroy": (C.c_int, [C.c_void_p]),

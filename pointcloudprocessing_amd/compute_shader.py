@@ -280,7 +280,13 @@ class ComputeShader:
         debug_data = np.zeros((n, 4), dtype=np.float32) if debug else None
         size = float(np.asarray(voxel_size).reshape(-1)[0])
         np_points = np.asarray(np_points)
-        if np_points.dtype == np.float32 and np_points.ndim == 2 and np_points.shape[1] == 3 and np_points.flags.c_contiguous:
+        if (np_points.dtype == np.float32 and np_points.ndim == 2 and np_points.shape[1] == 3 and n > 1
+                and np_points.T.flags.c_contiguous and not np_points.flags.c_contiguous):
+            # float32 coordinate rows (a transposed cloud): interleaved and padded on the device
+            check(self._lib.pcp_voxelize_rows(self._ctx, f32p(np_points.T), n, size, int(stored_voxel_num),
+                                              int(begin_index), int(max_points_to_store), i32p(unknown_points),
+                                              unknown_len, f32p(debug_data)))
+        elif np_points.dtype == np.float32 and np_points.ndim == 2 and np_points.shape[1] == 3 and np_points.flags.c_contiguous:
             # already float32 (x, y, z): the zero fourth component of pad_points is added on the device
             check(self._lib.pcp_voxelize_xyz(self._ctx, f32p(np_points), n, size, int(stored_voxel_num),
                                              int(begin_index), int(max_points_to_store), i32p(unknown_points),

@@ -89,6 +89,12 @@ __global__ void k_pad_xyz(const float* __restrict__ xyz, int n, float4* __restri
     if (i < n) out[i] = make_float4(xyz[3 * (size_t)i + 0], xyz[3 * (size_t)i + 1], xyz[3 * (size_t)i + 2], 0.0f);
 }
 
+// three coordinate rows of n floats each (a transposed cloud as it lies in memory) -> the same records
+__global__ void k_pad_rows(const float* __restrict__ rows, int n, float4* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = make_float4(rows[i], rows[(size_t)n + i], rows[2 * (size_t)n + i], 0.0f);
+}
+
 // VoxelShader.glsl:100-146
 __global__ void __launch_bounds__(256)
 k_voxelize(const float4* __restrict__ pts, int n, const int4* __restrict__ table, int stored,
@@ -456,6 +462,11 @@ int pcp_voxelize_xyz(pcp_ctx* c, const float* pts_xyz, int n, float voxel_size, 
     return voxelize_impl(c, pts_xyz, 3, n, voxel_size, stored, begin_index, max_points, unknown, unknown_len, debug);
 }
 
+int pcp_voxelize_rows(pcp_ctx* c, const float* xyz_rows, int n, float voxel_size, int stored, int begin_index,
+                      int max_points, int32_t* unknown, int unknown_len, float* debug) {
+    return voxelize_impl(c, xyz_rows, -3, n, voxel_size, stored, begin_index, max_points, unknown, unknown_len, debug);
+}
+
 static int voxelize_impl(pcp_ctx* c, const float* pts_xyzw, int floats_per_point, int n, float voxel_size, int stored,
                          int begin_index, int max_points, int32_t* unknown, int unknown_len, float* debug) {
     if (int e = use(c)) return e;
@@ -482,7 +493,8 @@ static int voxelize_impl(pcp_ctx* c, const float* pts_xyzw, int floats_per_point
         // expansion has read them: one stream) and are widened on the device
         float* staging = reinterpret_cast<float*>(v->debug);
         PCP_CHECK(hipMemcpyAsync(staging, pts_xyzw, (size_t)n * 3 * sizeof(float), hipMemcpyHostToDevice, c->stream));
-        hipLaunchKernelGGL(k_pad_xyz, dim3(cdiv(n, 256)), dim3(256), 0, c->stream, staging, n, v->pts);
+        if (floats_per_point == 3) hipLaunchKernelGGL(k_pad_xyz, dim3(cdiv(n, 256)), dim3(256), 0, c->stream, staging, n, v->pts);
+        else hipLaunchKernelGGL(k_pad_rows, dim3(cdiv(n, 256)), dim3(256), 0, c->stream, staging, n, v->pts);
         PCP_CHECK(hipGetLastError());
     }
     hipLaunchKernelGGL(k_voxelize, dim3(cdiv(n, 256)), dim3(256), 0, c->stream, v->pts, n, v->table, stored, v->data,

@@ -240,7 +240,14 @@ class Voxelizer:
         it is written into added_points / added_colors (float32 (cap, 4) / (cap, 3), capacity doubling
         as in the reference) when one of the two is next looked at: the per-frame path never reads them."""
         n = len(np_points)
-        pts = np.array(np.asarray(np_points)[:, :3], dtype=np.float32, order="C")   # the caller may reuse its array
+        src = np.asarray(np_points)[:, :3]
+        if src.T.flags.c_contiguous and not src.flags.c_contiguous:
+            # a transposed (3, n) cloud, e.g. (R @ p.T).T of LidarDataReader.py:66-67: the float32 copy keeps the
+            # coordinate rows (a contiguous cast; into (n, 3) order it is a strided one, five times slower) and
+            # the device interleaves them
+            pts = np.array(src.T, dtype=np.float32, order="C").T
+        else:
+            pts = np.array(src, dtype=np.float32, order="C")                 # the caller may reuse its array
         cols = None if colors is None else np.array(colors, dtype=np.float32)
         self._pending.append((self.last_added_point, pts, cols))
         self.last_added_point += n

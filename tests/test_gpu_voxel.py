@@ -299,3 +299,27 @@ def test_voxel_insertion_error_paths(compute):
     assert lib.pcp_voxel_insert_unknown(ctx, 1024, C.byref(stored), C.byref(cap)) != 0      # already consumed
     with pytest.raises(RuntimeError):
         v.addPoints(np.array([[3e6, 0.0, 0.0]]), None)                                        # beyond +-2^20 voxels
+
+
+def test_transposed_clouds_are_fed_as_coordinate_rows(compute):
+    """The reference hands over (R @ p.T).T (LidarDataReader.py:66-67), a transposed array: its float32 copy keeps
+    the coordinate rows and the device interleaves them.  Same map, same point store as with an (n, 3)-ordered copy."""
+    maps = []
+    for transposed in (True, False):
+        v = Voxelizer(compute, None)
+        v.init(0.5)
+        for frame in kitti_pair():
+            rows = np.ascontiguousarray(np.asarray(frame).T)             # (3, n) in memory
+            cloud = rows.T if transposed else np.ascontiguousarray(rows.T)
+            assert cloud.flags.c_contiguous != transposed
+            v.addPoints(cloud, None)
+            assert v._pending[-1][1].flags.c_contiguous != transposed
+        s = v.stored_voxels
+        maps.append((v.voxel_index[:s].copy(), v.voxel_data[:s, 0].copy(),
+                     [np.sort(v.voxel_data[r, 1:min(v.voxel_data[r, 0] + 1, v.max_points)]) for r in range(0, s, 97)],
+                     v.added_points[:v.last_added_point, :3].copy(), v.added_colors[:v.last_added_point].copy()))
+    a, b = maps
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[0], G["voxel_index"][:len(a[0])])
+    assert all(np.array_equal(x, y) for x, y in zip(a[2], b[2]))
+    assert np.array_equal(a[3], b[3]) and np.array_equal(a[4], b[4]) and np.all(a[4] == 255.0)
+    assert np.array_equal(a[3], np.vstack(kitti_pair()).astype(np.float32))
