@@ -296,6 +296,70 @@ __device__ __forceinline__ int find_closest(const Target& T, const float4 q, flo
     return glob;
 }
 
+// The all-rings search (hint -1) of find_closest with K lanes per query, K a power of two <= 64 and the
+// K lanes adjacent: lane `sub` takes the offsets k = sub, sub + K, ... of the same outward walk, the K
+// running minima are shared after every round (they only serve the bound tests, and a ring whose lower
+// bound exceeds ANY distance already found can neither hold nor tie the minimum), and the results are
+// merged by the same order (smaller distance, then lower ring).  Returns the ring find_closest would
+// leave in the hint, -1 if no ring produced a comparable distance.  `live` lanes hold a query; every
+// lane of the wave must call.
+template <int K>
+__device__ __forceinline__ int first_ring(const Target& T, const bool live, const float4 q, const int sub) {
+    const float4 v = make_float4(q.x - T.o.x, (q.y - T.o.y) - PCP_LIDAR_OFF_Y, q.z - T.o.z, q.w - T.o.w);
+    const float rho2 = dot4(v, v);
+    const float len = sqrtf(rho2);
+    const float4 ref = make_float4(v.x / len, v.y / len, v.z / len, v.w / len);
+    const float sq = ref.y;
+    const float cq = sqrtf(ref.x * ref.x + ref.z * ref.z + ref.w * ref.w);
+    const bool can_prune = cq > 0.05f;
+    const gf4_t my_bins = T.bins + (size_t)az_bin(ref.x, ref.z) * T.Z;
+    const float far = (v.x * v.x + v.z * v.z) * PCP_AZ_FAR;
+    const int from = 0, to = T.Zs;
+    int centre = 0;
+    if (can_prune) {                 // the K lanes share the scan for the most promising ring (first of the smallest bounds)
+        float lo = PCP_BIG;
+        for (int r = from + sub; r < to; r += K) {
+            const float lb = ring_lower_bound(T.stat[r], sq, cq, rho2);
+            if (lb < lo) { lo = lb; centre = r; }
+        }
+#pragma unroll
+        for (int s = 1; s < K; s <<= 1) {
+            const float olo = __shfl_xor(lo, s, 64);
+            const int oc = __shfl_xor(centre, s, 64);
+            if (olo < lo || (olo == lo && oc < centre)) { lo = olo; centre = oc; }
+        }
+    }
+    const int last = live ? 2 * max(centre - from, to - 1 - centre) : -1;
+    float mind = PCP_BIG, shared = PCP_BIG;
+    int ring = -1;
+    for (int k0 = 0; __any(k0 <= last); k0 += K) {
+        const int k = k0 + sub;
+        const int r = centre + ((k & 1) ? (k + 1) / 2 : -(k / 2));
+        bool visit = k <= last && r >= from && r < to;
+        if (visit && can_prune && shared < PCP_BIG) {
+            if (ring_lower_bound(T.stat[r], sq, cq, rho2) > shared) visit = false;
+            else if (ring_bin_lower_bound(ld4(my_bins, r), sq, cq, rho2, far) > shared) visit = false;
+        }
+        if (visit) {
+            const int2 se = T.scan[r];
+            int best;
+            float d;
+            ring_window<10, false>(T, q, ref, se.x, se.y, -1, best, d);
+            if (d < mind || (d == mind && ring >= 0 && r < ring)) { mind = d; ring = r; }
+        }
+        shared = fminf(shared, mind);
+#pragma unroll
+        for (int s = 1; s < K; s <<= 1) shared = fminf(shared, __shfl_xor(shared, s, 64));
+    }
+#pragma unroll
+    for (int s = 1; s < K; s <<= 1) {
+        const float od = __shfl_xor(mind, s, 64);
+        const int orr = __shfl_xor(ring, s, 64);
+        if (orr >= 0 && (ring < 0 || od < mind || (od == mind && orr < ring))) { mind = od; ring = orr; }
+    }
+    return ring;
+}
+
 __device__ __forceinline__ float nan0(const float v) { return (v != v) ? 0.0f : v; }
 
 // Upper-triangle index of (i, j), i <= j, in the 27-value record.

@@ -358,6 +358,31 @@ __global__ void __launch_bounds__(PCP_BLOCK) k_ls(const LsArgs A) {
     ls_body<MODE, F64SRC>(A, smem, blockIdx.x);
 }
 
+// Iteration 0 of the device loop on a freshly prepared pair searches all rings (hint -1), and with one
+// pair in flight that launch is a couple of waves per SIMD whose slowest lanes walk 60 rings one after
+// the other: a third to a half of a whole registration.  This pre-pass finds the ring that search ends on
+// with K lanes per query and leaves it in the hint; the iteration's own search then covers the four
+// rings around it, which hold the all-rings winner (the point of smallest distance on the lowest such
+// ring is also the first of any subset of rings that contains its ring), so every result is unchanged.
+template <int K>
+__global__ void __launch_bounds__(PCP_BLOCK) k_first_rings(const LsArgs A) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int2* s_scan;
+    const float4* s_stat;
+    load_rings(smem, A.scan, A.stat, A.Z, s_scan, s_stat);
+    const unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = (int)(t / K), sub = (int)(t % K);
+    bool live = i < A.n_b;
+    float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (live) {
+        live = A.hint[i] == -1.0f;
+        q = make_float4((float)A.b_in[3 * (size_t)i + 0], (float)A.b_in[3 * (size_t)i + 1], (float)A.b_in[3 * (size_t)i + 2], 0.0f);
+    }
+    const Target T{as_global(A.a), as_global(A.ua), s_scan, s_stat, as_global(A.bins), A.n_a, A.Z, A.Zs, A.o};
+    const int ring = first_ring<K>(T, live, q, sub);
+    if (live && sub == 0 && ring >= 0) A.hint[i] = (float)ring;
+}
+
 // The same for a batch of independent pairs.
 #ifndef PCP_LS_WAVES
 #define PCP_LS_WAVES 8      // resident waves per SIMD the register budget is set for
@@ -848,6 +873,25 @@ int pcp_icp_launch(pcp_ctx* c, int mode, int max_iter, float tol, int full_iter)
     if (max_iter == 0)
         PCP_CHECK(hipMemcpyAsync(c->b64, c->b_in, (size_t)c->n_b * 3 * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
     c->prof_used = 0;
+    if (max_iter > 0) {
+        // lanes per query of the all-rings pre-pass; PCP_FIRST_LANES=0 in the environment leaves the first
+        // iteration to its own search (same results either way)
+        static const int lanes = [] {
+            const char* e = getenv("PCP_FIRST_LANES");
+            const int v = e ? atoi(e) : 8;
+            return (v == 4 || v == 8 || v == 16 || v == 32) ? v : (v == 0 ? 0 : 8);
+        }();
+        if (lanes) {
+            const LsArgs A = ls_args(c, 0, nullptr);
+            const dim3 grid(cdiv(c->n_b * lanes, PCP_BLOCK)), block(PCP_BLOCK);
+            const size_t sm = scan_smem(c);
+            if (lanes == 4) hipLaunchKernelGGL(k_first_rings<4>, grid, block, sm, c->stream, A);
+            else if (lanes == 8) hipLaunchKernelGGL(k_first_rings<8>, grid, block, sm, c->stream, A);
+            else if (lanes == 16) hipLaunchKernelGGL(k_first_rings<16>, grid, block, sm, c->stream, A);
+            else hipLaunchKernelGGL(k_first_rings<32>, grid, block, sm, c->stream, A);
+            PCP_CHECK(hipGetLastError());
+        }
+    }
     for (int it = 0; it < max_iter; ++it) {
         if (c->profile) {
             while ((int)c->prof_events.size() < 2 * (it + 1)) {

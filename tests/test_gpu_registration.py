@@ -389,6 +389,10 @@ def test_ragged_ring_layouts_match_oracle_bitwise(compute, seed):
     H, bb = compute.dispatchPointPlane(b)
     rH, rb = spl.dispatch_plane(b)
     assert np.array_equal(bits(H), bits(rH)) and np.array_equal(bits(bb), bits(rb))
+    # the device loop, whose first iteration finds its rings with several lanes per query, starts from that tile
+    from pointcloudprocessing_amd import MODE_PLANE
+    _, _, hb, _ = compute.icpRun(b, MODE_PLANE, 2, full_iter=True, want_hb=True)
+    assert np.array_equal(bits(hb[0][:6, :6]), bits(rH)) and np.array_equal(bits(hb[0][:6, 6]), bits(rb))
 
 
 # ------------------------------------------------------------------------------ largest ring table
