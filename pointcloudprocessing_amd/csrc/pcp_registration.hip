@@ -365,12 +365,11 @@ __global__ void __launch_bounds__(PCP_BLOCK) k_ls(const LsArgs A) {
 // rings around it, which hold the all-rings winner (the point of smallest distance on the lowest such
 // ring is also the first of any subset of rings that contains its ring), so every result is unchanged.
 template <int K>
-__global__ void __launch_bounds__(PCP_BLOCK) k_first_rings(const LsArgs A) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+__device__ __forceinline__ void first_rings_body(const LsArgs& A, char* smem, const unsigned block) {
     const int2* s_scan;
     const float4* s_stat;
     load_rings(smem, A.scan, A.stat, A.Z, s_scan, s_stat);
-    const unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned t = block * blockDim.x + threadIdx.x;
     const int i = (int)(t / K), sub = (int)(t % K);
     bool live = i < A.n_b;
     float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -381,6 +380,12 @@ __global__ void __launch_bounds__(PCP_BLOCK) k_first_rings(const LsArgs A) {
     const Target T{as_global(A.a), as_global(A.ua), s_scan, s_stat, as_global(A.bins), A.n_a, A.Z, A.Zs, A.o};
     const int ring = first_ring<K>(T, live, q, sub);
     if (live && sub == 0 && ring >= 0) A.hint[i] = (float)ring;
+}
+
+template <int K>
+__global__ void __launch_bounds__(PCP_BLOCK) k_first_rings(const LsArgs A) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    first_rings_body<K>(A, smem, blockIdx.x);
 }
 
 // The same for a batch of independent pairs.
