@@ -360,6 +360,29 @@ __device__ __forceinline__ int first_ring(const Target& T, const bool live, cons
     return ring;
 }
 
+// One ring of the hinted search of find_closest (rings [max(0, h-2), min(Z, h+2))): ring from + sub, its
+// window minimum in (mind, glob), ring = -1 when the ring is outside the range or yields no distance.
+// The caller merges sub = 0..3 in that order with a strict '<', which is the shader's loop; no ring is
+// skipped, which changes nothing (a skipped ring can neither hold nor tie the minimum).
+__device__ __forceinline__ void hinted_ring(const Target& T, const bool live, const float4 q, const int sub,
+                                            const float hint, float& mind, int& glob, int& ring) {
+    const float4 v = make_float4(q.x - T.o.x, (q.y - T.o.y) - PCP_LIDAR_OFF_Y, q.z - T.o.z, q.w - T.o.w);
+    const float len = sqrtf(dot4(v, v));
+    const float4 ref = make_float4(v.x / len, v.y / len, v.z / len, v.w / len);   // == unit_sphere(q, o)
+    const int h = (int)hint;
+    const int r = max(0, h - 2) + sub;
+    mind = PCP_BIG;
+    glob = 0;
+    ring = -1;
+    if (live && r < min(T.Z, h + 2)) {
+        const int2 se = T.scan[r];
+        int best;
+        float d;
+        ring_window<10, false>(T, q, ref, se.x, se.y, -1, best, d);
+        if (d < mind) { mind = d; glob = best; ring = r; }
+    }
+}
+
 __device__ __forceinline__ float nan0(const float v) { return (v != v) ? 0.0f : v; }
 
 // Upper-triangle index of (i, j), i <= j, in the 27-value record.

@@ -358,6 +358,90 @@ __global__ void __launch_bounds__(PCP_BLOCK) k_ls(const LsArgs A) {
     ls_body<MODE, F64SRC>(A, smem, blockIdx.x);
 }
 
+// ls_body<MODE, true> for a single pair in flight.  Such a launch is two waves per SIMD, each walking
+// 2.4 ring passes of 14 dependent memory round trips: its time is that chain, not the work.  Here a
+// block of four waves serves the 64 points of one shader workgroup: wave w searches ring from + w of
+// every point's four hinted rings (so a wave's gathers still go to one stretch of one ring), the four
+// results meet in LDS, and the first wave merges them in ring order, computes the tile values of the 64
+// points and their tree sum exactly as ls_body does.  Points whose hint is still -1 are searched by
+// their lane of the first wave over all rings.  Same results; the batched launches keep ls_body (they
+// fill the GPU, and the unpruned rings would be wasted work there).
+template <int MODE>
+__global__ void __launch_bounds__(256) k_ls_quad(const LsArgs A) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ float s_d[4][64];
+    __shared__ int s_glob[4][64], s_ring[4][64];
+    IcpState* __restrict__ st = A.st;
+    if (st->done) return;
+    const int2* s_scan;
+    const float4* s_stat;
+    load_rings(smem, A.scan, A.stat, A.Z, s_scan, s_stat);
+    const int t = threadIdx.x, qi = t & 63, sub = t >> 6;
+    const int i = blockIdx.x * 64 + qi;
+    const bool in = i < A.n_b;
+    float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+    double px = 0.0, py = 0.0, pz = 0.0;
+    bool moved = false;
+    if (in) {
+        const bool first = st->iter == 0;       // iteration 0 reads the cloud as uploaded
+        const double* rd = first ? A.b_in : A.b64;
+        px = rd[3 * (size_t)i + 0]; py = rd[3 * (size_t)i + 1]; pz = rd[3 * (size_t)i + 2];
+        if (st->pending) {
+            const double nx = ((st->R[0] * px + st->R[1] * py) + st->R[2] * pz) - st->t[0];
+            const double ny = ((st->R[3] * px + st->R[4] * py) + st->R[5] * pz) - st->t[1];
+            const double nz = ((st->R[6] * px + st->R[7] * py) + st->R[8] * pz) - st->t[2];
+            px = nx; py = ny; pz = nz;
+        }
+        moved = st->pending || first;
+        q = make_float4((float)px, (float)py, (float)pz, 0.0f);
+    }
+    const Target T{as_global(A.a), as_global(A.ua), s_scan, s_stat, as_global(A.bins), A.n_a, A.Z, A.Zs, A.o};
+    float h = in ? A.hint[i] : -1.0f;
+    const bool quad = in && h != -1.0f;
+    float mind;
+    int glob, ring;
+    hinted_ring(T, quad, q, sub, h, mind, glob, ring);
+    s_d[sub][qi] = mind;
+    s_glob[sub][qi] = glob;
+    s_ring[sub][qi] = ring;
+    __syncthreads();
+    if (sub != 0) return;
+    float v[PCP_NVAL];
+#pragma unroll
+    for (int k = 0; k < PCP_NVAL; ++k) v[k] = 0.0f;
+    if (in) {
+        // all four waves have read the point by the barrier above: only now is the moved one stored
+        if (moved) { A.b64[3 * (size_t)i + 0] = px; A.b64[3 * (size_t)i + 1] = py; A.b64[3 * (size_t)i + 2] = pz; }
+        int nn = 0;
+        if (quad) {
+            float best = PCP_BIG;
+            int won = -1;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const float d = s_d[w][qi];
+                if (s_ring[w][qi] >= 0 && d < best) { best = d; nn = s_glob[w][qi]; won = s_ring[w][qi]; }
+            }
+            if (won >= 0) h = (float)won;
+        } else {
+            nn = find_closest(T, q, h);
+        }
+        A.hint[i] = h;
+        const float4 pa = ld4(T.a, nn);
+        const float d = distsq(q, pa);
+        if (MODE == PCP_MODE_POINT) ls_point_values(pa, q, d, v);
+        else ls_plane_values(pa, q, ld4(as_global(A.normals), nn), d, v);
+    }
+#pragma unroll
+    for (int k = 0; k < PCP_NVAL; ++k) v[k] = wave_tree_sum(v[k]);
+    float mine = 0.0f;
+#pragma unroll
+    for (int k = 0; k < PCP_NVAL; ++k) {
+        const float vk = __shfl(v[k], 0, 64);
+        mine = (qi == k) ? vk : mine;
+    }
+    if (qi < PCP_PSTRIDE) A.partials[(size_t)blockIdx.x * PCP_PSTRIDE + qi] = mine;
+}
+
 // Iteration 0 of the device loop on a freshly prepared pair searches all rings (hint -1), and with one
 // pair in flight that launch is a couple of waves per SIMD whose slowest lanes walk 60 rings one after
 // the other: a third to a half of a whole registration.  This pre-pass finds the ring that search ends on
@@ -906,7 +990,15 @@ int pcp_icp_launch(pcp_ctx* c, int mode, int max_iter, float tol, int full_iter)
             }
             PCP_CHECK(hipEventRecord(c->prof_events[2 * it], c->stream));
         }
-        if (int e = launch_ls(c, mode, true, 0, nullptr)) return e;
+        static const bool quad = [] { const char* e = getenv("PCP_LS_QUAD"); return !(e && e[0] == '0'); }();
+        if (quad) {       // PCP_LS_QUAD=0 in the environment runs the one-lane-per-point kernel (same results)
+            if (int e = check_ls(c, mode, 0)) return e;
+            const LsArgs A = ls_args(c, 0, nullptr);
+            const dim3 grid(cdiv(c->n_b, 64)), block(256);
+            if (mode == PCP_MODE_POINT) hipLaunchKernelGGL(k_ls_quad<PCP_MODE_POINT>, grid, block, scan_smem(c), c->stream, A);
+            else hipLaunchKernelGGL(k_ls_quad<PCP_MODE_PLANE>, grid, block, scan_smem(c), c->stream, A);
+            PCP_CHECK(hipGetLastError());
+        } else if (int e = launch_ls(c, mode, true, 0, nullptr)) return e;
         if (c->profile) {
             PCP_CHECK(hipEventRecord(c->prof_events[2 * it + 1], c->stream));
             c->prof_used = it + 1;

@@ -390,9 +390,21 @@ def test_ragged_ring_layouts_match_oracle_bitwise(compute, seed):
     rH, rb = spl.dispatch_plane(b)
     assert np.array_equal(bits(H), bits(rH)) and np.array_equal(bits(bb), bits(rb))
     # the device loop, whose first iteration finds its rings with several lanes per query, starts from that tile
-    from pointcloudprocessing_amd import MODE_PLANE
-    _, _, hb, _ = compute.icpRun(b, MODE_PLANE, 2, full_iter=True, want_hb=True)
+    # (a pre-pass over all rings, then four waves per 64 points on the hinted rings), starts from that tile and
+    # goes on exactly like the batched launches, which search with one lane per point
+    from pointcloudprocessing_amd import IcpBatch
+    dx, cv, hb, moved = compute.icpRun(b, MODE_PLANE, 3, full_iter=True, want_hb=True, want_points=True)
     assert np.array_equal(bits(hb[0][:6, :6]), bits(rH)) and np.array_equal(bits(hb[0][:6, 6]), bits(rb))
+    batch = IcpBatch([compute])
+    try:
+        batch.upload_sources([b])
+        batch.prepare(True)
+        batch.launch(MODE_PLANE, 3, full_iter=True)
+        (dx2, cv2, hb2, moved2), = batch.results(3, want_hb=True, want_points=True)
+    finally:
+        batch.close()
+    assert len(dx) == len(dx2) and np.array_equal(bits(dx), bits(dx2)) and np.array_equal(bits(hb), bits(hb2))
+    assert np.array_equal(moved.view(np.uint64), moved2.view(np.uint64))
 
 
 # ------------------------------------------------------------------------------ largest ring table
