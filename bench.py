@@ -188,6 +188,22 @@ def main():
         if (tr.get("pairs_per_launch"), tr.get("n_a"), tr.get("n_b")) == (args.pairs, n_a, n_b):
             traffic = tr["fetch_bytes_per_launch"] + tr["write_bytes_per_launch"]
 
+    # latency of ONE registration with nothing else in flight (not part of `value`): source upload, hint
+    # reset, the whole iteration loop and the fetch of the steps, target kept prepared on the device
+    for bt in batches:
+        bt.close()
+    batches = []
+    single = None
+    if rank == 0:
+        b0 = moved_copy(a, 1000 * rank)[0]
+        times = []
+        for _ in range(13):
+            c0 = time.perf_counter()
+            dx0, _, _, _ = pairs[0].cs.icpRun(b0, MODE_PLANE, MAX_ITER, tol=TOL)
+            times.append(time.perf_counter() - c0)
+        single = {"ms": float(np.median(times[3:]) * 1e3), "iterations": int(len(dx0)),
+                  "what": "one pair alone on the GPU: upload of the 3 MB source, the iteration loop, fetch of the steps"}
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import np_oracle as O
@@ -226,6 +242,7 @@ def main():
                          "avg_launch_us": avg_launch_s * 1e6, "launches_timed": ls_launches,
                          "algorithmic_bytes_per_launch": alg_bytes},
             "cpu_baseline": cpu,
+            "single_pair": single,
         }
         print(json.dumps(out))
     for bt in batches:
