@@ -366,13 +366,15 @@ __global__ void __launch_bounds__(PCP_BLOCK) k_ls(const LsArgs A) {
 // points and their tree sum exactly as ls_body does.  Points whose hint is still -1 are searched by
 // their lane of the first wave over all rings.  Same results; the batched launches keep ls_body (they
 // fill the GPU, and the unpruned rings would be wasted work there).
-template <int MODE>
+template <int MODE, bool F64SRC>
 __global__ void __launch_bounds__(256) k_ls_quad(const LsArgs A) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ float s_d[4][64];
     __shared__ int s_glob[4][64], s_ring[4][64];
     IcpState* __restrict__ st = A.st;
-    if (st->done) return;
+    if (F64SRC) {
+        if (st->done) return;
+    }
     const int2* s_scan;
     const float4* s_stat;
     load_rings(smem, A.scan, A.stat, A.Z, s_scan, s_stat);
@@ -382,7 +384,7 @@ __global__ void __launch_bounds__(256) k_ls_quad(const LsArgs A) {
     float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
     double px = 0.0, py = 0.0, pz = 0.0;
     bool moved = false;
-    if (in) {
+    if (in && F64SRC) {
         const bool first = st->iter == 0;       // iteration 0 reads the cloud as uploaded
         const double* rd = first ? A.b_in : A.b64;
         px = rd[3 * (size_t)i + 0]; py = rd[3 * (size_t)i + 1]; pz = rd[3 * (size_t)i + 2];
@@ -394,6 +396,8 @@ __global__ void __launch_bounds__(256) k_ls_quad(const LsArgs A) {
         }
         moved = st->pending || first;
         q = make_float4((float)px, (float)py, (float)pz, 0.0f);
+    } else if (in) {
+        q = A.b32[i];
     }
     const Target T{as_global(A.a), as_global(A.ua), s_scan, s_stat, as_global(A.bins), A.n_a, A.Z, A.Zs, A.o};
     float h = in ? A.hint[i] : -1.0f;
@@ -448,7 +452,7 @@ __global__ void __launch_bounds__(256) k_ls_quad(const LsArgs A) {
 // with K lanes per query and leaves it in the hint; the iteration's own search then covers the four
 // rings around it, which hold the all-rings winner (the point of smallest distance on the lowest such
 // ring is also the first of any subset of rings that contains its ring), so every result is unchanged.
-template <int K>
+template <int K, bool F64SRC>
 __device__ __forceinline__ void first_rings_body(const LsArgs& A, char* smem, const unsigned block) {
     const int2* s_scan;
     const float4* s_stat;
@@ -459,17 +463,18 @@ __device__ __forceinline__ void first_rings_body(const LsArgs& A, char* smem, co
     float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
     if (live) {
         live = A.hint[i] == -1.0f;
-        q = make_float4((float)A.b_in[3 * (size_t)i + 0], (float)A.b_in[3 * (size_t)i + 1], (float)A.b_in[3 * (size_t)i + 2], 0.0f);
+        if (F64SRC) q = make_float4((float)A.b_in[3 * (size_t)i + 0], (float)A.b_in[3 * (size_t)i + 1], (float)A.b_in[3 * (size_t)i + 2], 0.0f);
+        else q = A.b32[i];
     }
     const Target T{as_global(A.a), as_global(A.ua), s_scan, s_stat, as_global(A.bins), A.n_a, A.Z, A.Zs, A.o};
     const int ring = first_ring<K>(T, live, q, sub);
     if (live && sub == 0 && ring >= 0) A.hint[i] = (float)ring;
 }
 
-template <int K>
+template <int K, bool F64SRC>
 __global__ void __launch_bounds__(PCP_BLOCK) k_first_rings(const LsArgs A) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    first_rings_body<K>(A, smem, blockIdx.x);
+    first_rings_body<K, F64SRC>(A, smem, blockIdx.x);
 }
 
 // The same for a batch of independent pairs.
@@ -653,6 +658,44 @@ int launch_finish(pcp_ctx* c, int solve, int mode, int max_iter, float tol, int 
     return 0;
 }
 
+// The two kernels that serve a single pair in flight (the device loop, and the stepwise dispatches of
+// prepareLS / dispatchLS and friends): the all-rings pre-pass and the four-wave search.  Both leave every
+// result as the one-lane kernel does.  PCP_FIRST_LANES=0 / PCP_LS_QUAD=0 in the environment switch them off.
+template <bool F64SRC>
+int launch_first_rings(pcp_ctx* c) {
+    static const int lanes = [] {
+        const char* e = getenv("PCP_FIRST_LANES");
+        const int v = e ? atoi(e) : 8;
+        return (v == 4 || v == 8 || v == 16 || v == 32) ? v : (v == 0 ? 0 : 8);
+    }();
+    if (!lanes) return 0;
+    const LsArgs A = ls_args(c, 0, nullptr);
+    const dim3 grid(cdiv(c->n_b * lanes, PCP_BLOCK)), block(PCP_BLOCK);
+    const size_t sm = scan_smem(c);
+    if (lanes == 4) hipLaunchKernelGGL((k_first_rings<4, F64SRC>), grid, block, sm, c->stream, A);
+    else if (lanes == 8) hipLaunchKernelGGL((k_first_rings<8, F64SRC>), grid, block, sm, c->stream, A);
+    else if (lanes == 16) hipLaunchKernelGGL((k_first_rings<16, F64SRC>), grid, block, sm, c->stream, A);
+    else hipLaunchKernelGGL((k_first_rings<32, F64SRC>), grid, block, sm, c->stream, A);
+    PCP_CHECK(hipGetLastError());
+    return 0;
+}
+
+bool use_quad() {
+    static const bool quad = [] { const char* e = getenv("PCP_LS_QUAD"); return !(e && e[0] == '0'); }();
+    return quad;
+}
+
+template <bool F64SRC>
+int launch_ls_quad(pcp_ctx* c, int mode) {
+    if (int e = check_ls(c, mode, 0)) return e;
+    const LsArgs A = ls_args(c, 0, nullptr);
+    const dim3 grid(cdiv(c->n_b, 64)), block(256);
+    if (mode == PCP_MODE_POINT) hipLaunchKernelGGL((k_ls_quad<PCP_MODE_POINT, F64SRC>), grid, block, scan_smem(c), c->stream, A);
+    else hipLaunchKernelGGL((k_ls_quad<PCP_MODE_PLANE, F64SRC>), grid, block, scan_smem(c), c->stream, A);
+    PCP_CHECK(hipGetLastError());
+    return 0;
+}
+
 int ls_stepwise(pcp_ctx* c, const float* b_xyzw, int n_b, int mode, int debug, float* hb, float* tiles_host) {
     if (int e = use(c)) return e;
     if (int e = upload_b32(c, b_xyzw, n_b)) return e;
@@ -661,7 +704,11 @@ int ls_stepwise(pcp_ctx* c, const float* b_xyzw, int n_b, int mode, int debug, f
         if (int e = ensure_tiles(c)) return e;
         tiles = c->tiles;
     }
-    if (int e = launch_ls(c, mode, false, debug, tiles)) return e;
+    if (!debug && !tiles && use_quad()) {
+        if (int e = check_ls(c, mode, 0)) return e;
+        if (int e = launch_first_rings<false>(c)) return e;
+        if (int e = launch_ls_quad<false>(c, mode)) return e;
+    } else if (int e = launch_ls(c, mode, false, debug, tiles)) return e;
     if (hb) {
         if (int e = launch_finish(c, 0, mode, 0, 0.f, 0)) return e;
         PCP_CHECK(hipMemcpyAsync(hb, c->hb_trace, 64 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
@@ -854,6 +901,7 @@ int pcp_nn(pcp_ctx* c, const float* b_xyzw, int n_b, uint32_t* idx, float* dist2
     if (int e = use(c)) return e;
     if (!idx || !dist2) return pcp_fail("null output");
     if (int e = upload_b32(c, b_xyzw, n_b)) return e;
+    if (int e = launch_first_rings<false>(c)) return e;          // queries still without a hint: their ring, found by 8 lanes each
     hipLaunchKernelGGL(k_nn, dim3(cdiv(n_b, PCP_BLOCK)), dim3(PCP_BLOCK), scan_smem(c), c->stream, c->a, c->ua, c->scan, c->ring_stat, c->ring_bins,
                        c->n_a, c->n_scans, c->n_scans_search, c->origin, c->b32, n_b, c->hint, c->nn_idx, c->nn_dist);
     PCP_CHECK(hipGetLastError());
@@ -962,25 +1010,8 @@ int pcp_icp_launch(pcp_ctx* c, int mode, int max_iter, float tol, int full_iter)
     if (max_iter == 0)
         PCP_CHECK(hipMemcpyAsync(c->b64, c->b_in, (size_t)c->n_b * 3 * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
     c->prof_used = 0;
-    if (max_iter > 0) {
-        // lanes per query of the all-rings pre-pass; PCP_FIRST_LANES=0 in the environment leaves the first
-        // iteration to its own search (same results either way)
-        static const int lanes = [] {
-            const char* e = getenv("PCP_FIRST_LANES");
-            const int v = e ? atoi(e) : 8;
-            return (v == 4 || v == 8 || v == 16 || v == 32) ? v : (v == 0 ? 0 : 8);
-        }();
-        if (lanes) {
-            const LsArgs A = ls_args(c, 0, nullptr);
-            const dim3 grid(cdiv(c->n_b * lanes, PCP_BLOCK)), block(PCP_BLOCK);
-            const size_t sm = scan_smem(c);
-            if (lanes == 4) hipLaunchKernelGGL(k_first_rings<4>, grid, block, sm, c->stream, A);
-            else if (lanes == 8) hipLaunchKernelGGL(k_first_rings<8>, grid, block, sm, c->stream, A);
-            else if (lanes == 16) hipLaunchKernelGGL(k_first_rings<16>, grid, block, sm, c->stream, A);
-            else hipLaunchKernelGGL(k_first_rings<32>, grid, block, sm, c->stream, A);
-            PCP_CHECK(hipGetLastError());
-        }
-    }
+    if (max_iter > 0)
+        if (int e = launch_first_rings<true>(c)) return e;
     for (int it = 0; it < max_iter; ++it) {
         if (c->profile) {
             while ((int)c->prof_events.size() < 2 * (it + 1)) {
@@ -990,14 +1021,8 @@ int pcp_icp_launch(pcp_ctx* c, int mode, int max_iter, float tol, int full_iter)
             }
             PCP_CHECK(hipEventRecord(c->prof_events[2 * it], c->stream));
         }
-        static const bool quad = [] { const char* e = getenv("PCP_LS_QUAD"); return !(e && e[0] == '0'); }();
-        if (quad) {       // PCP_LS_QUAD=0 in the environment runs the one-lane-per-point kernel (same results)
-            if (int e = check_ls(c, mode, 0)) return e;
-            const LsArgs A = ls_args(c, 0, nullptr);
-            const dim3 grid(cdiv(c->n_b, 64)), block(256);
-            if (mode == PCP_MODE_POINT) hipLaunchKernelGGL(k_ls_quad<PCP_MODE_POINT>, grid, block, scan_smem(c), c->stream, A);
-            else hipLaunchKernelGGL(k_ls_quad<PCP_MODE_PLANE>, grid, block, scan_smem(c), c->stream, A);
-            PCP_CHECK(hipGetLastError());
+        if (use_quad()) {
+            if (int e = launch_ls_quad<true>(c, mode)) return e;
         } else if (int e = launch_ls(c, mode, true, 0, nullptr)) return e;
         if (c->profile) {
             PCP_CHECK(hipEventRecord(c->prof_events[2 * it + 1], c->stream));
