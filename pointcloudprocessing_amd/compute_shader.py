@@ -169,7 +169,9 @@ class ComputeShader:
         self.corr_out[:, 1] = dist
         self.corr_out[:, 2] = 0
         self.corr_out[:, 3] = hint
-        return self.corr_out[:, 0].astype(np.uint32), self.corr_out[:, 1].astype(np.float32)
+        # the reference returns corr_out[:, 0].astype(uint32), corr_out[:, 1].astype(float32): indices below 2^24
+        # survive the float32 column unchanged, so these are the same arrays without two strided passes
+        return idx, dist
 
     # ------------------------------------------------------------------ hierarchical sum
     def hbSum(self, tiles):
