@@ -43,6 +43,7 @@ class ComputeShader:
         self._ctx = C.c_void_p()
         check(self._lib.pcp_create(int(device), int(maxPointsPerCloud), int(maxScans), C.byref(self._ctx)))
         self._active = None          # which prepare* ran last
+        self._frame = None           # device frame of prepareTargetOnDevice, made on first use
         self._n_source = None        # points of the float64 source IcpBatch.upload_sources sent last
         self._voxel_resident = None  # voxel count of a map whose device copy is the authority, else None
         self.reallocate_out(np.array([maxPointsPerCloud, maxPointsPerCloud, 0, 0]))
@@ -130,6 +131,25 @@ class ComputeShader:
         scan_lines = self.padScanlines(scan_lines)
         self.saveUniformInfo(points_a, points_b, origin, scan_lines, debug_mode)
         self._active = "plane"
+
+    def prepareTargetOnDevice(self, points_a, points_b, origin, point_to_plane):
+        """prepareLS (:491-515) / preparePointPlane (:571-585) for a float64 cloud with the host passes of the
+        reference done on the device: the ring segmentation of PointcloudIcpContainer.getScanLines (:362-392,
+        pcp_frame_scan_lines), pad_points and the float32 cast (:956-961, :301-316); the cloud goes up once as
+        float64.  Same target, scan lines and normals as the host path; returns the scan lines."""
+        from .frame import DeviceFrame
+        if self._frame is None:
+            self._frame = DeviceFrame(max_points=self.maxPointsPerCloud, device=self.device, max_scans=self.maxScans)
+        self._frame.upload(points_a)
+        lines = self._frame.scan_lines(origin)
+        self.target_serial = getattr(self, "target_serial", 0) + 1
+        self._frame.as_target(self, lines, origin, point_to_plane)          # sets _active
+        if point_to_plane:
+            lines4 = self.padScanlines(lines)
+        else:
+            lines4 = np.ones((len(lines), 4), dtype=np.uint32)
+        self.saveUniformInfo(points_a, points_b, origin, lines4, False)
+        return lines
 
     def resetHints(self, n_points_b=None):
         """What every prepare* does to the ring hints (corr.w = -1, ComputeShader.py:488-489,
@@ -337,6 +357,9 @@ class ComputeShader:
 
     def cleanup(self):
         """:966-998"""
+        if getattr(self, "_frame", None) is not None:
+            self._frame.cleanup()
+            self._frame = None
         if self._ctx:
             self._lib.pcp_destroy(self._ctx)
             self._ctx = C.c_void_p()

@@ -22,6 +22,9 @@ class PointcloudIcpContainer:
         # that array in place.  The reference prepares every call (PointcloudIcpContainer.py:72,104).
         self.keep_prepared_target = False
         self._kept = None
+        # preparePointToPoint / preparePointToPlane of a float64 cloud run their host passes (scan lines,
+        # padding, cast) on the device; False keeps them in NumPy as the reference has them (same results)
+        self.device_prepare = True
 
     # ------------------------------------------------------------------ scan lines (:349-392)
     def sphereProjectPont(self, point, origin):
@@ -49,8 +52,18 @@ class PointcloudIcpContainer:
         return scan_lines
 
     # ------------------------------------------------------------------ stepwise protocol
+    def _on_device(self, points_a):
+        """True when the reference cloud can be prepared by the device (ComputeShader.prepareTargetOnDevice:
+        ring segmentation, padding and cast there instead of in NumPy): a float64 (n, 3+) array that fits."""
+        return (self.device_prepare and hasattr(self.compute, "prepareTargetOnDevice") and isinstance(points_a, np.ndarray)
+                and points_a.dtype == np.float64 and points_a.ndim == 2 and points_a.shape[1] >= 3
+                and 0 < len(points_a) <= getattr(self.compute, "maxPointsPerCloud", 0))
+
     def preparePointToPoint(self, points_a, origin, points_b):
         """:20-22"""
+        if self._on_device(points_a):
+            self.compute.prepareTargetOnDevice(points_a, points_b, origin, False)
+            return
         self.compute.prepareLS(points_a, self.getScanLines(points_a, origin), points_b, origin, False)
 
     def dispatchPointToPoint(self, points_b):
@@ -62,6 +75,9 @@ class PointcloudIcpContainer:
 
     def preparePointToPlane(self, points_a, origin, points_b):
         """:31-39"""
+        if self._on_device(points_a):
+            self.compute.prepareTargetOnDevice(points_a, points_b, origin, True)
+            return
         self.compute.preparePointPlane(points_a, self.getScanLines(points_a, origin), points_b, origin, False)
 
     def dispatchPointToPlane(self, points_b):
