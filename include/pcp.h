@@ -348,6 +348,9 @@ int pcp_frame_decode(pcp_frame* frame, const float* raw_xyzi, size_t n, float mi
                      size_t* n_out);
 /* Make an existing float64 cloud the resident one. */
 int pcp_frame_upload(pcp_frame* frame, const double* xyz, size_t n);
+/* The same for a cloud held as three coordinate rows of n float64 each (a transposed (3, n) array such as
+ * (R @ points.T).T of LidarDataReader.py:66-67 as it lies in memory); interleaved on the device. */
+int pcp_frame_upload_rows(pcp_frame* frame, const double* x, const double* y, const double* z, size_t n);
 /* p <- R p + t on the resident cloud. */
 int pcp_frame_move(pcp_frame* frame, const double* R9, const double* t3);
 /* getScanLines on the resident cloud: lines receives (begin, end_inclusive) pairs. */

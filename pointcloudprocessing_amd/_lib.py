@@ -91,6 +91,7 @@ SIGNATURES = {
     "pcp_frame_destroy": (C.c_int, [C.c_void_p]),
     "pcp_frame_decode": (C.c_int, [C.c_void_p, _f32p, C.c_size_t, C.c_float, _f64p, C.POINTER(C.c_size_t)]),
     "pcp_frame_upload": (C.c_int, [C.c_void_p, _f64p, C.c_size_t]),
+    "pcp_frame_upload_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "pcp_frame_move": (C.c_int, [C.c_void_p, _f64p, _f64p]),
     "pcp_frame_scan_lines": (C.c_int, [C.c_void_p, _f64p, C.c_int, _u32p, _i32p]),
     "pcp_frame_read": (C.c_int, [C.c_void_p, _f64p, _f32p]),

@@ -91,6 +91,13 @@ inline unsigned blocks_for(size_t n, int threads) { return (unsigned)((n + threa
 
 }  // namespace
 
+__global__ void k_interleave_rows(const double* __restrict__ x, const double* __restrict__ y, const double* __restrict__ z,
+                                  size_t n, double* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    out[3 * i + 0] = x[i]; out[3 * i + 1] = y[i]; out[3 * i + 2] = z[i];
+}
+
 struct pcp_frame {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -173,6 +180,28 @@ int pcp_frame_upload(pcp_frame* f, const double* xyz, size_t n) {
     if (n && !xyz) return pcp_fail("xyz is null");
     PCP_CHECK(hipSetDevice(f->device));
     if (n) PCP_CHECK(hipMemcpyAsync(f->xyz, xyz, n * 24, hipMemcpyHostToDevice, f->stream));
+    PCP_CHECK(hipStreamSynchronize(f->stream));
+    f->n = n;
+    return 0;
+}
+
+int pcp_frame_upload_rows(pcp_frame* f, const double* x, const double* y, const double* z, size_t n) {
+    if (!f) return pcp_fail("null frame");
+    if (n > f->cap) return pcp_fail("%zu points exceed the frame capacity %zu", n, f->cap);
+    if (n && (!x || !y || !z)) return pcp_fail("a coordinate row is null");
+    PCP_CHECK(hipSetDevice(f->device));
+    if (n) {
+        // staging in buffers this call owns anyway: x and z in the two halves of the raw records (16 B per
+        // point), y in the float32 copy (rebuilt from the cloud when it is next asked for)
+        double* sx = reinterpret_cast<double*>(f->raw);
+        double* sz = sx + n;
+        double* sy = reinterpret_cast<double*>(f->xyzw32);
+        PCP_CHECK(hipMemcpyAsync(sx, x, n * 8, hipMemcpyHostToDevice, f->stream));
+        PCP_CHECK(hipMemcpyAsync(sy, y, n * 8, hipMemcpyHostToDevice, f->stream));
+        PCP_CHECK(hipMemcpyAsync(sz, z, n * 8, hipMemcpyHostToDevice, f->stream));
+        hipLaunchKernelGGL(k_interleave_rows, dim3(blocks_for(n, 256)), dim3(256), 0, f->stream, sx, sy, sz, n, f->xyz);
+        PCP_CHECK(hipGetLastError());
+    }
     PCP_CHECK(hipStreamSynchronize(f->stream));
     f->n = n;
     return 0;

@@ -39,6 +39,14 @@ class DeviceFrame:
         return self.decode(np.fromfile(path, dtype=np.float32).reshape(-1, 4), min_range, rotation)
 
     def upload(self, np_points):
+        pts = np.asarray(np_points)
+        cols = pts[:, :3].T if pts.ndim == 2 else None
+        if cols is not None and pts.dtype == np.float64 and len(pts) > 1 and cols.flags.c_contiguous:
+            # a transposed cloud: its three coordinate rows go up as they lie
+            row, base = cols.strides[0], cols.ctypes.data
+            check(self._lib.pcp_frame_upload_rows(self._f, base, base + row, base + 2 * row, len(pts)))
+            self.n = len(pts)
+            return
         p = np.ascontiguousarray(np.asarray(np_points, dtype=np.float64)[:, :3])
         check(self._lib.pcp_frame_upload(self._f, f64p(p), len(p)))
         self.n = len(p)
