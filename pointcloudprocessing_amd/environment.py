@@ -78,7 +78,9 @@ class EnvironmentConstructor:
         return (r_opt @ estimated_position.T).T - t_opt
 
     def applyOptimalTranslation(self, r_opt, t_opt, points):
-        return (r_opt @ points.T).T - t_opt
+        """:101-102 -- (r_opt @ points.T).T - t_opt; the offset is taken from the (3, n) product before the
+        transposition (the same subtraction element by element, on contiguous rows)."""
+        return (r_opt @ points.T - np.asarray(t_opt)[:, None]).T
 
     def getCurrentOxtsData(self, current_oxts):
         """:104-105"""
@@ -122,7 +124,7 @@ class EnvironmentConstructor:
                                                current_rotation=current_rotation, prev_time=p_time)
         estimated_position = p_refined_pos + delta_velocity
         next_pure_imu_position = p_imu_pos + delta_velocity
-        aligned_points = (current_rotation @ points.T).T + estimated_position
+        aligned_points = (current_rotation @ points.T + estimated_position[:, None]).T     # == (R @ p.T).T + position
 
         if not pure_imu:
             full_iteration = False
