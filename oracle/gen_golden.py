@@ -11,6 +11,8 @@ Needs /root/reference (read-only).  Three kinds of vectors:
   ref_arena.npz    the reference's point arena (GpuMemoryManager) through a scripted alloc/free sequence
   ref_imu.npz      the reference's odometry driver in IMU-only mode over the sample OXTS records
   ref_kd.npz       the reference's legacy KD-tree ICP (icp_step_KD, align_KD) on the pair
+  ref_normals.npz  the reference's own pure-Python statement of the ring normals
+                   (tests/GpuTest.py:325-455, getNormals) on the first 50,000 points of frame 0
   oracle_kitti.npz outputs of oracle/np_oracle.py on the KITTI pair (full-size
                    parity targets for the HIP kernels, so GPU tests need not
                    rerun the slow NumPy search)
@@ -167,6 +169,34 @@ def ref_kd(frames):
     np.savez_compressed(os.path.join(OUT, "ref_kd.npz"), **out)
 
 
+def ref_normals(frames):
+    """The reference's independent pure-Python statement of NormalShader.glsl, GpuTest.getNormals
+    (tests/GpuTest.py:325-455), called exactly as test_shouldGetSameNormalsFromGpu does (:297-309): frame 0,
+    origin 0, the scan lines of getScanLines unpadded, float64, the first 50,000 points.  The test module
+    imports ComputeShader (GL-only: OpenGL, glfw) at its top; an empty stand-in module satisfies that import,
+    getNormals itself only calls PointcloudIcpContainer.sphereProjectPont."""
+    import types
+    sys.path.insert(0, REF)
+    sys.path.insert(0, os.path.join(REF, "tests"))
+    if "ComputeShader" not in sys.modules:
+        m = types.ModuleType("ComputeShader")
+        m.ComputeShader = type("ComputeShader", (), {})
+        sys.modules["ComputeShader"] = m
+    import contextlib
+    import io
+    from GpuTest import GpuTest
+    from PointcloudIcpContainer import PointcloudIcpContainer
+    icp = PointcloudIcpContainer(None, None)
+    pts = frames[0]
+    origin = np.array([0, 0, 0])
+    scan_lines = icp.getScanLines(pts, origin)
+    with contextlib.redirect_stdout(io.StringIO()):
+        normals = GpuTest.getNormals(scan_lines, pts, origin, icp)
+    normals = np.array(normals)
+    np.savez_compressed(os.path.join(OUT, "ref_normals.npz"), n_points=len(normals), frame_sha=sha(pts),
+                        normals64=normals, normals=np.insert(normals.astype(np.float32), 3, 0, axis=1))
+
+
 def ref_imu():
     """The reference's odometry driver in its IMU-only mode (EnvironmentConstructor.calculateTransition_imu
     with pure_imu=True, :154-265) over the OXTS records of sample_data, with a 40-point stand-in cloud per
@@ -286,6 +316,8 @@ if __name__ == "__main__":
         ref_arena()
     if "--no-imu" not in sys.argv:
         ref_imu()
+    if "--no-normals" not in sys.argv:
+        ref_normals(frames)
     if "--no-kd" not in sys.argv:
         ref_kd(frames)
     if "--no-voxel" not in sys.argv:

@@ -88,6 +88,21 @@ def test_normals_kitti_matches_golden(compute):
     assert O_sha(compute.normals_out_a) == str(g["normals_sha"])
 
 
+def test_normals_equal_the_reference_getNormals(compute):
+    """tests/GpuTest.py:297-323 as the reference runs it: prepareDispatchNormals on frame 0, the first
+    50,000 rows of normals_out_a against GpuTest.getNormals (fixture ref_normals.npz), > 99.9 % within 1e-3."""
+    ref = golden("ref_normals.npz")
+    a, _ = kitti_pair()
+    icp = PointcloudIcpContainer(compute)
+    lines = icp.getScanLines(a, ORIGIN)
+    compute.prepareDispatchNormals(a, lines, ORIGIN)
+    normals = compute.normals_out_a[:50000]
+    diff = normals - ref["normals"]
+    assert (np.linalg.norm(diff, axis=1) < 1e-3).mean() > 0.999
+    same = np.linalg.norm(normals[:, :3].astype(np.float64) - ref["normals64"], axis=1) < 1e-5
+    assert same.mean() > 0.9997        # same neighbours picked as the reference's search, see the CPU test
+
+
 # ------------------------------------------------------------------------------ LS tiles + tree sum (a-4, a-5, a-6)
 def test_ls_point_tiles_and_sum_match_oracle_bitwise(compute):
     a, b = small_pair()
