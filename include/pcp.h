@@ -93,6 +93,16 @@ int pcp_hb_sum(pcp_ctx* ctx, const float* tiles /* n x 64 */, int n, float* out 
  * no host sync. */
 int pcp_hb_sum_dev(pcp_ctx* ctx, const float* tiles_dev, int n, float* scratch_dev,
                    float* out_dev /* 64 */);
+/* pcp_hb_sum_dev without a workspace argument and without any allocation: the tree's intermediate
+ * levels live in a fixed array inside the library's code object (1.04 MB per GPU, held until the
+ * process ends).  No counterpart in the reference; it is for callers that cannot allocate device
+ * memory where they call from: code under HIP graph capture, tight serving loops, harnesses that forbid
+ * hipMalloc.  n <= 262144 tiles (64 MB of tiles; the reference's buffers hold 200000), larger n fail
+ * with a message.  Same kernels and same result, bit for bit, as pcp_hb_sum_dev.  Enqueues on the
+ * context's stream, no host sync.  All calls on one GPU share that GPU's array: calls that overlap
+ * on one GPU (different contexts or streams) race and must be serialised by the caller.  Nothing in
+ * the array has to be cleared between calls: every level overwrites what the next one reads. */
+int pcp_hb_sum_static(pcp_ctx* ctx, const float* tiles_dev, int n, float* out_dev /* 64 */);
 
 /* Device-resident iteration loop of PointcloudIcpContainer.full_pt2pt (:71-100)
  * and full_pt2pl (:103-144): per iteration the fused NN + tile + tree-sum

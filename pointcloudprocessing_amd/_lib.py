@@ -43,6 +43,7 @@ SIGNATURES = {
     "pcp_ls_tiles": (C.c_int, [_ctx, _f32p, C.c_int, C.c_int, C.c_int, _f32p]),
     "pcp_hb_sum": (C.c_int, [_ctx, _f32p, C.c_int, _f32p]),
     "pcp_hb_sum_dev": (C.c_int, [_ctx, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "pcp_hb_sum_static": (C.c_int, [_ctx, C.c_void_p, C.c_int, C.c_void_p]),
     "pcp_icp_run": (C.c_int, [_ctx, _f64p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int,
                               _f32p, _f32p, _i32p, _i32p, _f64p]),
     "pcp_upload_source": (C.c_int, [_ctx, _f64p, C.c_int]),

@@ -17,6 +17,7 @@
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
+#include <mutex>
 #include <vector>
 
 #include "../../include/pcp.h"
@@ -582,6 +583,45 @@ inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
 }  // namespace
 
+// ---- fixed scratch of pcp_hb_sum_static ----------------------------------------------------
+// The intermediate tree levels of up to PCP_HB_STATIC_MAX_TILES tiles: ceil(n/64) tiles of level 1 and
+// ceil(n/4096) of level 2 (level 3 reuses the front).  Part of the code object: every GPU the library
+// runs on holds its own copy (1.04 MB) at its own address until the process ends.  In host code the
+// array's NAME is only a handle for hipGetSymbolAddress; kernels receive the address that call
+// returned for the device they run on.
+#define PCP_HB_STATIC_MAX_TILES 262144
+#define PCP_HB_STATIC_FLOATS ((PCP_HB_STATIC_MAX_TILES / 64 + PCP_HB_STATIC_MAX_TILES / 4096) * 64)
+static __device__ __align__(256) float scratch[PCP_HB_STATIC_FLOATS];
+
+namespace {
+
+const int kMaxDevices = 64;
+float* g_hb_scratch[kMaxDevices];        // per device: device address of `scratch`, resolved once
+std::mutex g_hb_scratch_mutex;
+
+// Resolves the device address of `scratch` on `device` (which must be the current device).
+// Called from pcp_create, i.e. before any context of that device exists.
+int hb_scratch_bind(int device) {
+    if (device < 0 || device >= kMaxDevices) return pcp_fail("device %d beyond the %d the scratch table covers", device, kMaxDevices);
+    std::lock_guard<std::mutex> lock(g_hb_scratch_mutex);
+    if (g_hb_scratch[device]) return 0;
+    float* ptr = nullptr;
+    const hipError_t e = hipGetSymbolAddress((void**)&ptr, HIP_SYMBOL(scratch));
+    if (e != hipSuccess || !ptr) return pcp_fail("hipGetSymbolAddress(scratch) on device %d: %s", device, hipGetErrorString(e));
+    g_hb_scratch[device] = ptr;
+    return 0;
+}
+
+int hb_scratch_of(int device, float** out) {
+    std::lock_guard<std::mutex> lock(g_hb_scratch_mutex);
+    if (device < 0 || device >= kMaxDevices || !g_hb_scratch[device])
+        return pcp_fail("no scratch address for device %d (contexts come from pcp_create, which resolves it)", device);
+    *out = g_hb_scratch[device];
+    return 0;
+}
+
+}  // namespace
+
 namespace {
 
 int use(pcp_ctx* c) {
@@ -746,6 +786,7 @@ int pcp_create(int device, int max_points, int max_scans, pcp_ctx** out) {
     PCP_CHECK(hipGetDeviceCount(&ndev));
     if (device < 0 || device >= ndev) return pcp_fail("device %d not present (%d visible)", device, ndev);
     PCP_CHECK(hipSetDevice(device));
+    if (int e = hb_scratch_bind(device)) return e;      // device address of the fixed scratch array, once per device
     pcp_ctx* c = new pcp_ctx();
     c->device = device;
     c->max_points = max_points;
@@ -928,13 +969,12 @@ int pcp_ls_tiles(pcp_ctx* c, const float* b_xyzw, int n_b, int mode, int debug, 
     return ls_stepwise(c, b_xyzw, n_b, mode, debug, nullptr, tiles);
 }
 
-int pcp_hb_sum_dev(pcp_ctx* c, const float* tiles_dev, int n, float* scratch_dev, float* out_dev) {
-    if (int e = use(c)) return e;
-    if (!tiles_dev || !scratch_dev || !out_dev) return pcp_fail("null argument");
-    if (n < 1) return pcp_fail("n = %d: nothing to sum", n);
-    // ComputeShader.py:682-707: levels ping-pong between two buffers until one block is left.
-    // Level 1 writes g1 = ceil(n/64) tiles to scratch[0, g1), level 2 writes ceil(g1/64) tiles
-    // behind them, level 3 reuses the front, and so on.
+// ComputeShader.py:682-707: levels ping-pong between two buffers until one block is left.
+// Level 1 writes g1 = ceil(n/64) tiles to scratch[0, g1), level 2 writes ceil(g1/64) tiles
+// behind them, level 3 reuses the front, and so on.  Every level writes all 64 floats of each
+// of its output tiles and reads only the tiles the level before wrote, so the scratch needs no
+// particular contents on entry.
+static int hb_levels(pcp_ctx* c, const float* tiles_dev, int n, float* scratch_dev, float* out_dev) {
     const int g1 = cdiv(n, 64);
     float* region[2] = {scratch_dev, scratch_dev + (size_t)g1 * 64};
     const float* in = tiles_dev;
@@ -949,6 +989,25 @@ int pcp_hb_sum_dev(pcp_ctx* c, const float* tiles_dev, int n, float* scratch_dev
         cur = groups;
     }
     return 0;
+}
+
+int pcp_hb_sum_dev(pcp_ctx* c, const float* tiles_dev, int n, float* scratch_dev, float* out_dev) {
+    if (int e = use(c)) return e;
+    if (!tiles_dev || !scratch_dev || !out_dev) return pcp_fail("null argument");
+    if (n < 1) return pcp_fail("n = %d: nothing to sum", n);
+    return hb_levels(c, tiles_dev, n, scratch_dev, out_dev);
+}
+
+int pcp_hb_sum_static(pcp_ctx* c, const float* tiles_dev, int n, float* out_dev) {
+    if (int e = use(c)) return e;
+    if (!tiles_dev || !out_dev) return pcp_fail("null argument");
+    if (n < 1) return pcp_fail("n = %d: nothing to sum", n);
+    if (n > PCP_HB_STATIC_MAX_TILES)
+        return pcp_fail("n = %d tiles exceed the %d the library's fixed scratch array holds; use pcp_hb_sum_dev with a "
+                        "workspace of your own", n, PCP_HB_STATIC_MAX_TILES);
+    float* ptr = nullptr;
+    if (int e = hb_scratch_of(c->device, &ptr)) return e;
+    return hb_levels(c, tiles_dev, n, ptr, out_dev);
 }
 
 int pcp_hb_sum(pcp_ctx* c, const float* tiles, int n, float* out) {
