@@ -4,6 +4,8 @@
 
 Needs /root/reference (read-only).  Three kinds of vectors:
   kitti_pair.npz   data: raw xyz of sample_data velodyne frames 0000000000 / 0000000001
+  kitti_seq.npz    data: raw xyz of frames 0000000002 ... 0000000011 (packed losslessly, lidar.pack_raw_frames);
+                   with kitti_pair.npz the first twelve frames, enough to cross the reference's 10-frame reset
   ref_kat.npz      outputs of the reference's OWN importable CPU functions
                    (PointcloudIcpContainer, PointcloudAlignment), the known
                    answers that pin the restatement in oracle/np_oracle.py
@@ -39,6 +41,19 @@ def kitti_pair():
            for i in (0, 1)]
     np.savez_compressed(os.path.join(OUT, "kitti_pair.npz"), raw0=raw[0], raw1=raw[1])
     return raw
+
+
+def kitti_seq(first=2, last=11):
+    from pointcloudprocessing_amd import lidar
+    d = os.path.join(REF, "sample_data/velodyne_points/data")
+    raw = [np.fromfile(os.path.join(d, f"{i:010d}.bin"), dtype=np.float32).reshape(-1, 4)[:, :3].copy()
+           for i in range(first, last + 1)]
+    packed = lidar.pack_raw_frames(raw)
+    for a, b in zip(raw, lidar.unpack_raw_frames(packed)):
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), "packing is not lossless for this frame"
+    packed["first_frame"] = np.int64(first)
+    packed["raw_sha"] = np.array([sha(r) for r in raw])
+    np.savez_compressed(os.path.join(OUT, "kitti_seq.npz"), **packed)
 
 
 def ref_kat(raw):
@@ -194,7 +209,7 @@ def ref_normals(frames):
         normals = GpuTest.getNormals(scan_lines, pts, origin, icp)
     normals = np.array(normals)
     np.savez_compressed(os.path.join(OUT, "ref_normals.npz"), n_points=len(normals), frame_sha=sha(pts),
-                        normals64=normals, normals=np.insert(normals.astype(np.float32), 3, 0, axis=1))
+                        normals64=normals)
 
 
 def ref_imu():
@@ -311,6 +326,7 @@ def oracle_kitti(frames):
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     raw = kitti_pair()
+    kitti_seq()
     frames = ref_kat(raw)
     if "--no-arena" not in sys.argv:
         ref_arena()

@@ -39,6 +39,30 @@ def load_velodyne_bin(path):
     return frame_from_raw(raw[:, :3])
 
 
+def pack_raw_frames(frames):
+    """Lossless compact container for raw velodyne xyz (float32, millimetre-quantised as KITTI stores
+    them): per frame k the first differences of the integer millimetres, coordinate by coordinate
+    (`d<k>`, int32 (3, n)), and the flat positions of negative zeros (`z<k>`).  Dict for np.savez."""
+    out = {"frames": np.int64(len(frames))}
+    for k, xyz in enumerate(frames):
+        xyz = np.ascontiguousarray(xyz, dtype=np.float32)
+        mm = np.rint(xyz.astype(np.float64) * 1000.0).astype(np.int64)
+        out[f"d{k}"] = np.diff(mm, axis=0, prepend=0).T.astype(np.int32)
+        out[f"z{k}"] = np.flatnonzero(np.signbit(xyz) & (xyz == 0)).astype(np.int64)
+    return out
+
+
+def unpack_raw_frames(npz):
+    """Inverse of pack_raw_frames: list of (n, 3) float32 arrays, bit for bit the packed ones."""
+    frames = []
+    for k in range(int(npz["frames"])):
+        mm = np.cumsum(npz[f"d{k}"].astype(np.int64), axis=1).T
+        xyz = np.ascontiguousarray((mm.astype(np.float64) / 1000.0).astype(np.float32))
+        xyz.reshape(-1)[npz[f"z{k}"]] = -0.0
+        frames.append(xyz)
+    return frames
+
+
 # ----------------------------------------------------------------------------- synthetic scene
 _BOXES = np.array([   # axis-aligned boxes (xmin, ymin, zmin, xmax, ymax, zmax), y is up
     [6.0, -1.73, -2.0, 10.5, 0.0, 0.2],

@@ -35,3 +35,12 @@ def small_pair(seed=0, rings=17, steps=310):
 def bits(a):
     """float32 array -> its bit patterns, so that comparisons are exact (NaN included)."""
     return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+@functools.lru_cache(maxsize=None)
+def kitti_sequence_raw():
+    """Raw xyz (float32) of sample_data velodyne frames 0000000000 ... 0000000011, in that order."""
+    g = golden("kitti_pair.npz")
+    seq = golden("kitti_seq.npz")
+    assert int(seq["first_frame"]) == 2
+    return [g["raw0"], g["raw1"]] + lidar.unpack_raw_frames(seq)

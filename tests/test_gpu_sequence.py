@@ -1,0 +1,102 @@
+"""Frame-to-frame odometry over the first twelve real frames of sample_data (2011_09_26 drive): far enough to
+cross the reference's 10-frame replacement of the reference cloud (EnvironmentConstructor.py:35, :250-254),
+after which the registration origin is no longer zero and the [ox, oy, oz, ox] upload (ComputeShader.py:436-437)
+shows in every unit vector."""
+import hashlib
+
+import numpy as np
+import pytest
+
+from oracle import np_oracle as O
+from pointcloudprocessing_amd import MODE_PLANE, ComputeShader, PointcloudIcpContainer, Voxelizer, lidar, odometry
+from pointcloudprocessing_amd.environment import EnvironmentConstructor
+from tests._data import bits, golden, kitti_sequence_raw
+from tests.test_environment_cpu import reader_from_golden
+
+pytestmark = pytest.mark.gpu
+
+N_FRAMES = 12
+SAMPLED = (3, 11)         # a frame against the first reference cloud, and the first one after the reset
+
+
+def test_packed_sequence_fixture_is_lossless():
+    seq = golden("kitti_seq.npz")
+    for raw, want in zip(kitti_sequence_raw()[2:], seq["raw_sha"]):
+        assert hashlib.sha256(np.ascontiguousarray(raw).tobytes()).hexdigest() == str(want)
+
+
+def test_driver_over_real_frames_crosses_the_reset():
+    imu = golden("ref_imu.npz")
+    ox = reader_from_golden(imu)
+    reader = lidar.LidarDataReader()
+    for k, raw in enumerate(kitti_sequence_raw()):
+        reader.add_frame(f"{k:010d}", np.column_stack([raw, np.zeros(len(raw), np.float32)]))     # decoded on the device
+    cs = ComputeShader(maxPointsPerCloud=200000, maxScans=100)
+    icp = PointcloudIcpContainer(cs)
+    env = EnvironmentConstructor(None, ox, reader, icp, cs, voxelizer=Voxelizer(cs, None))
+    calls = []
+    plain = env.getRefinedTransition
+
+    def recording(**kw):
+        out = plain(**kw)
+        calls.append((kw["reference_points"], np.array(kw["reference_origin"], dtype=np.float64), kw["points_to_refine"],
+                      kw["iterations"], kw["full_iter"], out))
+        return out
+
+    env.getRefinedTransition = recording
+    try:
+        env.init(0.5)
+        for _ in range(N_FRAMES):
+            frame, rec = env.getNextFrameData(0)
+            env.calculateTransition_imu(frame, rec, point_to_plane=True, iterations=10)       # UI.py:400
+        poses = env.prev_poses
+        # IMU half: the reference's own run (pure_imu) over the same records
+        assert np.array_equal(np.stack([p[0] for p in poses]), imu["imu_pos"][:N_FRAMES])
+        assert np.array_equal(np.stack([p[2] for p in poses]), imu["rotation"][:N_FRAMES])
+        # the frame that closes the block runs 15 full iterations, then its refined cloud is the reference
+        assert [c[3] for c in calls] == [10] * 9 + [15, 10] and [c[4] for c in calls] == [False] * 9 + [True, False]
+        assert calls[10][0] is env.reference_points and np.array_equal(calls[10][1], poses[10][1])
+        assert np.abs(calls[10][1]).max() > 1.0                   # origin 3 m from the start: the quirk is live
+        assert env.local_frame_counter == 1
+        # refined against dead-reckoned trajectory: ICP corrects the IMU path by centimetres per frame, not metres
+        refined = np.stack([p[1] for p in poses])
+        drift = np.linalg.norm(refined - imu["imu_pos"][:N_FRAMES], axis=1)
+        assert drift.max() < 0.5, drift
+        steps = np.linalg.norm(np.diff(refined, axis=0), axis=1)
+        assert np.all((steps > 0.25) & (steps < 0.45)), steps      # the car rolls about a third of a metre per sweep
+        assert env.voxelizer.stored_voxels > 12082                # more than frame 0 alone holds at 0.5 m
+        # two sampled registrations, every iteration of the device loop against the restatement, bit for bit
+        for k in SAMPLED:
+            ref_pts, origin, placed, iters, full_iter, (t_dev, R_dev) = calls[k - 1]
+            icp.keep_prepared_target = False
+            icp.preparePointToPlane(ref_pts, origin, placed)
+            dx, conv, hb, _ = cs.icpRun(placed, MODE_PLANE, iters, tol=1e-6, full_iter=full_iter, want_hb=True)
+            trace = []
+            t_ref, R_ref = O.full_pt2pl(ref_pts, placed, origin, iterations=iters, full_iter=full_iter, trace=trace)
+            assert len(dx) == len(trace)
+            for i, (H, b, d) in enumerate(trace):
+                assert np.array_equal(bits(hb[i][:6, :6]), bits(H)) and np.array_equal(bits(hb[i][:6, 6]), bits(b)), (k, i)
+                assert np.array_equal(bits(dx[i]), bits(d)), (k, i)
+            assert np.abs(R_dev - R_ref).max() < 1e-5 and np.abs(t_dev - t_ref).max() < 1e-4
+    finally:
+        env.cleanup()
+        cs.cleanup()
+        reader.cleanup()
+
+
+def test_batched_sequence_odometry_equals_pair_by_pair():
+    frames = [lidar.frame_from_raw(r) for r in kitti_sequence_raw()]
+    poses = odometry.sequence_odometry(frames, point_to_plane=True, iterations=10, batch_size=4)
+    cs = ComputeShader(maxPointsPerCloud=200000, maxScans=100)
+    icp = PointcloudIcpContainer(cs)
+    try:
+        single = [icp.full_pt2pl(frames[k], frames[k + 1], np.zeros(3), iterations=10) for k in range(N_FRAMES - 1)]
+    finally:
+        cs.cleanup()
+    from pointcloudprocessing_amd import sharding
+    want = sharding.compose_odometry(single)
+    for (R, t), (Rw, tw) in zip(poses, want):
+        assert np.array_equal(R, Rw) and np.array_equal(t, tw)
+    # the drive: a third of a metre per sweep
+    length = np.linalg.norm(poses[-1][1])
+    assert 3.0 < length < 4.5, length

@@ -152,13 +152,14 @@ def test_normals_equal_the_reference_getNormals():
     first 50,000 points of frame 0: more than 99.9 % must agree to |delta| < 1e-3.  ref_normals.npz holds
     what GpuTest.getNormals returned for that call (oracle/gen_golden.py: ref_normals)."""
     ref = golden("ref_normals.npz")
+    ref32 = np.insert(ref["normals64"].astype(np.float32), 3, 0, axis=1)      # as tests/GpuTest.py:308-309 casts it
     a, _ = kitti_pair()
     n = int(ref["n_points"])
     assert n == 50000 and str(ref["frame_sha"]) == str(K["frame0_sha"])
     lines = O.get_scan_lines(a, ZERO)
     n32 = O.normals(O.pad_points(a), O.origin4(ZERO), O.pad_scan_lines(lines).astype(np.int64), 100)[:n]
     # the reference's assertion, as it states it (float32 difference, 4 components)
-    ok = np.linalg.norm(n32 - ref["normals"], axis=1) < 1e-3
+    ok = np.linalg.norm(n32 - ref32, axis=1) < 1e-3
     assert ok.mean() > 0.999
     # and tighter than the reference asks: a normal built from the SAME two neighbours differs only by
     # float32 rounding, one built from other neighbours by O(1); so this counts the points on which the
