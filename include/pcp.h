@@ -372,6 +372,43 @@ int pcp_frame_read(pcp_frame* frame, double* xyz, float* intensity);
 int pcp_frame_points_dev(pcp_frame* frame, const double** xyz_dev, size_t* n);
 int pcp_frame_padded_dev(pcp_frame* frame, const float** xyzw_dev, size_t* n);
 
+/* ---------------------------------------------------------------------------
+ * A run of consecutive raw frames registered pair by pair as one stream of device work.
+ * Per frame the reference reads the velodyne file (LidarDataReader.eatBytes :144-150), filters and
+ * rotates it (:59-67), and per pair runs getScanLines (PointcloudIcpContainer.py:362-392), the
+ * prepare* uploads and normals (ComputeShader.py:491-515, :571-585) and the iteration loop with one
+ * read-back per iteration (full_pt2pt :71-100 / full_pt2pl :103-144, called once per frame by
+ * EnvironmentConstructor.getRefinedTransition :116-132).  Here frame k of a submission is the target of
+ * pair k and the source of pair k - 1; everything from the raw bytes to the solved steps runs on the
+ * device without a host wait in between, the upload of one submission overlapping the registration of
+ * the one before (separate copy stream).  Per-pair results are those of pcp_frame_decode +
+ * pcp_frame_scan_lines + pcp_set_target_dev + pcp_icp_launch, bit for bit.
+ * ------------------------------------------------------------------------- */
+typedef struct pcp_seq pcp_seq;
+
+/* Buffers for submissions of up to max_frames frames (max_frames - 1 pairs) of up to max_points raw points. */
+int pcp_seq_create(int device, int max_frames, int max_points, int max_scans, pcp_seq** out);
+int pcp_seq_destroy(pcp_seq* seq);
+/* Enqueue n_frames raw frames (raw_xyzi[f]: n_raw[f] float32 rows x, y, z, intensity, as a velodyne .bin
+ * holds them) and the registration of every consecutive pair: ego filter |p| > min_range, rotation R9
+ * (row-major float64), scan lines about origin3, then mode / max_iter (<= 32) / tol / full_iter as
+ * pcp_icp_launch.  Returns at once with a ticket; at most two submissions may be in flight.  The raw
+ * buffers must stay valid and unchanged until the ticket is collected; the copy only overlaps other
+ * work when they are page-locked (pcp_host_alloc). */
+int pcp_seq_submit(pcp_seq* seq, const float* const* raw_xyzi, const int* n_raw, int n_frames, float min_range,
+                   const double* R9, const double* origin3, int mode, int max_iter, float tol, int full_iter,
+                   int* ticket);
+/* Wait for a submission and fetch its results, pair p = (frame p <- frame p + 1): dx_trace receives
+ * dx_stride_iters x 6 floats per pair (the steps, zero beyond iters[p]), iters / converged one int per
+ * pair, n_points (or NULL) the points each of the n_frames frames kept.  Fails (after filling the outputs)
+ * if a pair could not run: more scan lines than max_scans (as ComputeShader.py:506-512), a target without
+ * a scan line, an empty source, singular normal equations. */
+int pcp_seq_collect(pcp_seq* seq, int ticket, float* dx_trace, int dx_stride_iters, int* iters, int* converged,
+                    int* n_points);
+/* Page-locked host memory for buffers handed to pcp_seq_submit (hipHostMalloc / hipHostFree). */
+int pcp_host_alloc(size_t bytes, void** out);
+int pcp_host_free(void* p);
+
 #ifdef __cplusplus
 }
 #endif

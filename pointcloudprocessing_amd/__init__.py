@@ -13,3 +13,4 @@ from .environment import EnvironmentConstructor  # noqa: F401
 from .frame import DeviceFrame  # noqa: F401
 from .oxts import OXTS, OxtsDataReader  # noqa: F401
 from .voxelizer import Voxelizer  # noqa: F401
+from .sequence import PinnedFrames, SequencePipeline  # noqa: F401

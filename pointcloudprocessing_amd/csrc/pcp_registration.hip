@@ -15,12 +15,14 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdarg.h>
+#include <stddef.h>
 #include <stdio.h>
 #include <string.h>
 #include <mutex>
 #include <vector>
 
 #include "../../include/pcp.h"
+#include "pcp_compact.h"
 #include "pcp_ctx.h"
 #include "pcp_device.h"
 #include "pcp_solve.h"
@@ -1406,3 +1408,5 @@ int pcp_timer_stop(pcp_ctx* c, float* ms) {
 }
 
 }  // extern "C"
+
+#include "pcp_sequence.inl"

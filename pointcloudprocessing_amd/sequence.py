@@ -1,0 +1,152 @@
+"""Frame-to-frame odometry of a run of raw velodyne frames as one stream of device work (pcp_seq_*).
+
+The per-frame loop of the reference -- read the file, filter and rotate it (LidarDataReader.py:59-67,
+:144-150), scan lines, prepare, the iteration loop (EnvironmentConstructor.getRefinedTransition :116-132
+-> PointcloudIcpContainer.full_pt2pl :103-144) -- for F consecutive frames at once: frame k is the target
+of pair k and the source of pair k - 1.  submit() returns at once; the upload of the next run overlaps
+the registration of the current one.  Per-pair steps are those of the one-pair path, bit for bit.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib, lidar
+from ._lib import check, f32p, f64p, i32p
+from .compute_shader import MODE_PLANE, MODE_POINT
+from .icp_container import PointcloudIcpContainer
+
+
+class PinnedFrames:
+    """Raw frames (N, 4) float32 copied once into page-locked host memory, so that their upload is a
+    true asynchronous copy.  Index it like a list."""
+
+    def __init__(self, raws):
+        self._lib = _lib.load()
+        self._ptrs, self.arrays = [], []
+        for raw in raws:
+            raw = np.asarray(raw, dtype=np.float32)
+            if raw.ndim != 2 or raw.shape[1] not in (3, 4):
+                raise ValueError("a raw frame is (N, 4) float32 rows x, y, z, intensity (or (N, 3): intensity 0)")
+            p = C.c_void_p()
+            check(self._lib.pcp_host_alloc(max(1, raw.shape[0]) * 16, C.byref(p)))
+            self._ptrs.append(p)
+            a = np.ctypeslib.as_array((C.c_float * (4 * max(1, raw.shape[0]))).from_address(p.value)).reshape(-1, 4)[:len(raw)]
+            a[:, :raw.shape[1]] = raw
+            if raw.shape[1] == 3:
+                a[:, 3] = 0.0
+            self.arrays.append(a)
+
+    def __len__(self):
+        return len(self.arrays)
+
+    def __getitem__(self, k):
+        return self.arrays[k]
+
+    def close(self):
+        self.arrays = []
+        for p in self._ptrs:
+            self._lib.pcp_host_free(p)
+        self._ptrs = []
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class SequencePipeline:
+    def __init__(self, max_frames, max_points=131072, max_scans=100, device=0):
+        self._lib = _lib.load()
+        self._seq = C.c_void_p()
+        check(self._lib.pcp_seq_create(int(device), int(max_frames), int(max_points), int(max_scans), C.byref(self._seq)))
+        self.max_frames, self.max_points, self.max_scans, self.device = int(max_frames), int(max_points), int(max_scans), int(device)
+        self._runs = {}          # ticket -> (frames kept alive, n_frames, iterations, point_to_plane, full_iter)
+        self._icp = PointcloudIcpContainer(None)
+
+    def submit(self, raw_frames, origin=None, point_to_plane=True, iterations=10, tol=1e-6, full_iter=False,
+               min_range=2.5, rotation=None):
+        """raw_frames: sequence of (N, 4) float32 C-contiguous arrays (rows of a velodyne .bin), e.g. a
+        PinnedFrames or a list of its items; they must not change until collect().  Returns a ticket."""
+        frames = [raw_frames[k] for k in range(len(raw_frames))]
+        for a in frames:
+            if not (isinstance(a, np.ndarray) and a.dtype == np.float32 and a.ndim == 2 and a.shape[1] == 4
+                    and a.flags.c_contiguous):
+                raise ValueError("raw frames must be C-contiguous (N, 4) float32 arrays")
+        ptrs = (C.c_void_p * len(frames))(*[a.ctypes.data for a in frames])
+        sizes = np.array([len(a) for a in frames], dtype=np.int32)
+        R = np.ascontiguousarray(lidar.aligning_rotation() if rotation is None else rotation, dtype=np.float64)
+        o = np.zeros(3) if origin is None else np.ascontiguousarray(origin, dtype=np.float64)
+        ticket = C.c_int(-1)
+        check(self._lib.pcp_seq_submit(self._seq, ptrs, i32p(sizes), len(frames), float(min_range), f64p(R), f64p(o),
+                                       MODE_PLANE if point_to_plane else MODE_POINT, int(iterations), float(tol),
+                                       int(bool(full_iter)), C.byref(ticket)))
+        self._runs[ticket.value] = (frames, len(frames), int(iterations), bool(point_to_plane), bool(full_iter))
+        return ticket.value
+
+    def collect(self, ticket):
+        """-> (steps, n_points): steps[p] = (dx trace (iters, 6) float32, converged) of pair p = (frame p <- frame p + 1),
+        n_points[f] = points frame f kept after the ego filter."""
+        frames, n_frames, iterations, plane, full_iter = self._runs.pop(ticket)
+        P = n_frames - 1
+        dx = np.zeros((P, iterations, 6), dtype=np.float32)
+        iters = np.zeros(P, dtype=np.int32)
+        conv = np.zeros(P, dtype=np.int32)
+        n_pts = np.zeros(n_frames, dtype=np.int32)
+        check(self._lib.pcp_seq_collect(self._seq, int(ticket), f32p(dx), iterations, i32p(iters), i32p(conv), i32p(n_pts)))
+        return [(dx[p, :iters[p]].copy(), bool(conv[p])) for p in range(P)], n_pts
+
+    def poses(self, steps, point_to_plane=True, full_iter=False):
+        """(t_opt, R_opt) per pair from its steps, as full_pt2pl / full_pt2pt return them
+        (PointcloudIcpContainer.py:140, :333-347): p <- R_opt p - t_opt maps frame p + 1 into frame p."""
+        out = []
+        for dx, conv in steps:
+            applied = len(dx) - 1 if (conv and point_to_plane and not full_iter) else len(dx)
+            out.append(self._icp._replay(dx, applied))
+        return out
+
+    def close(self):
+        if self._seq:
+            self._lib.pcp_seq_destroy(self._seq)
+            self._seq = C.c_void_p()
+        self._runs = {}
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def sequence_odometry_raw(raw_frames, point_to_plane=True, iterations=10, rank=0, world=1, device=0, chunk=64,
+                          gather_device="cpu", max_points=131072):
+    """Poses of every frame in the frame of the first, [(R_w, t_w)] with p0 = R_w p + t_w, from raw velodyne
+    frames.  Pairs are dealt to the ranks in contiguous blocks (a rank then decodes every frame of its
+    block once), each block runs through a SequencePipeline in chunks of `chunk` pairs; poses are gathered
+    once (sharding.gather_poses) and chained on the host."""
+    from . import sharding
+    n_pairs = len(raw_frames) - 1
+    per = -(-n_pairs // world)
+    lo, hi = min(n_pairs, rank * per), min(n_pairs, (rank + 1) * per)
+    local = {}
+    if hi > lo:
+        pinned = PinnedFrames(raw_frames[lo:hi + 1])
+        pipe = SequencePipeline(min(chunk, hi - lo) + 1, max_points=max_points, device=device)
+        try:
+            pending = []
+            for c0 in range(0, hi - lo, chunk):
+                c1 = min(hi - lo, c0 + chunk)
+                pending.append((c0, pipe.submit([pinned[k] for k in range(c0, c1 + 1)], point_to_plane=point_to_plane,
+                                                iterations=iterations)))
+                if len(pending) == 2:
+                    b0, t = pending.pop(0)
+                    for j, pose in enumerate(pipe.poses(pipe.collect(t)[0], point_to_plane)):
+                        local[lo + b0 + j] = pose
+            for b0, t in pending:
+                for j, pose in enumerate(pipe.poses(pipe.collect(t)[0], point_to_plane)):
+                    local[lo + b0 + j] = pose
+        finally:
+            pipe.close()
+            pinned.close()
+    poses = sharding.gather_poses(local, n_pairs, rank, world, device=gather_device)
+    return sharding.compose_odometry(poses)

@@ -32,7 +32,9 @@ def gather_poses(local, n_pairs, rank, world, device="cpu"):
     import torch.distributed as dist
     per_rank = -(-n_pairs // world)
     block = torch.full((per_rank, 13), -1.0, dtype=torch.float64, device=device)
-    for slot, k in enumerate(pairs_of_rank(n_pairs, rank, world)):
+    if len(local) > per_rank:
+        raise ValueError("a rank holds more pairs than ceil(n_pairs / world)")
+    for slot, k in enumerate(sorted(local)):            # round robin or contiguous blocks: any split that is even
         block[slot, 0] = float(k)
         block[slot, 1:] = torch.from_numpy(pack_pose(*local[k])).to(device)
     blocks = [torch.empty_like(block) for _ in range(world)]

@@ -100,3 +100,81 @@ def test_batched_sequence_odometry_equals_pair_by_pair():
     # the drive: a third of a metre per sweep
     length = np.linalg.norm(poses[-1][1])
     assert 3.0 < length < 4.5, length
+
+
+# ------------------------------------------------------------------------------ the one-stream pipeline (pcp_seq_*)
+def _raw4(raw3):
+    return np.ascontiguousarray(np.column_stack([raw3, np.zeros(len(raw3), np.float32)]), dtype=np.float32)
+
+
+@pytest.mark.parametrize("plane,iterations", [(True, 10), (False, 6)])
+def test_pipeline_equals_the_pair_by_pair_device_path(plane, iterations):
+    """Raw bytes in, steps out: every pair's dx trace, convergence flag and point counts equal those of
+    DeviceFrame.decode + scan_lines + as_target + pcp_icp_launch on the same frames, bit for bit."""
+    from pointcloudprocessing_amd import PinnedFrames, SequencePipeline
+    from pointcloudprocessing_amd.frame import DeviceFrame, register_frames
+    raws = [_raw4(r) for r in kitti_sequence_raw()]
+    pinned = PinnedFrames(raws)
+    pipe = SequencePipeline(max_frames=N_FRAMES, max_points=131072)
+    cs = ComputeShader(maxPointsPerCloud=131072, maxScans=100)
+    fa, fb = DeviceFrame(131072), DeviceFrame(131072)
+    try:
+        # two submissions in flight: a short run first (5 frames), then all twelve
+        t_short = pipe.submit([pinned[k] for k in range(5)], point_to_plane=plane, iterations=iterations)
+        t_all = pipe.submit(pinned, point_to_plane=plane, iterations=iterations)
+        with pytest.raises(Exception, match="in flight"):
+            pipe.submit(pinned, point_to_plane=plane, iterations=iterations)
+        short, n_short = pipe.collect(t_short)
+        steps, n_pts = pipe.collect(t_all)
+        assert len(short) == 4 and len(steps) == N_FRAMES - 1
+        for p in range(4):
+            assert np.array_equal(bits(short[p][0]), bits(steps[p][0])) and short[p][1] == steps[p][1]
+        poses = pipe.poses(steps, plane)
+        for p in range(N_FRAMES - 1):
+            assert fa.decode(raws[p]) == n_pts[p] and fb.decode(raws[p + 1]) == n_pts[p + 1]
+            (t_opt, R_opt), dx, conv = register_frames(cs, fa, fb, np.zeros(3), point_to_plane=plane, iterations=iterations)
+            assert conv == steps[p][1] and np.array_equal(bits(dx), bits(steps[p][0])), p
+            assert np.array_equal(t_opt, poses[p][0]) and np.array_equal(R_opt, poses[p][1])
+    finally:
+        fa.cleanup()
+        fb.cleanup()
+        cs.cleanup()
+        pipe.close()
+        pinned.close()
+
+
+def test_pipeline_reports_pairs_that_cannot_run():
+    from pointcloudprocessing_amd import PcpError, SequencePipeline
+    raws = [_raw4(r) for r in kitti_sequence_raw()[:2]]
+    rng = np.random.default_rng(0)
+    # a frame of 5 points that never wrap in azimuth has no ring: it cannot be a target, and as a source it
+    # leaves the normal equations singular
+    flat = np.column_stack([rng.uniform(5, 6, 5), rng.uniform(0.1, 0.2, 5), rng.uniform(-1, 1, 5), np.zeros(5)]).astype(np.float32)
+    pipe = SequencePipeline(max_frames=4, max_points=131072)
+    try:
+        with pytest.raises(PcpError, match="pair 0.*no scan line"):
+            pipe.collect(pipe.submit([flat, raws[0], raws[1]], iterations=3))
+        with pytest.raises(PcpError, match="pair 0: singular normal equations at iteration 0"):
+            pipe.collect(pipe.submit([raws[0], flat], iterations=3))
+        with pytest.raises(PcpError, match="source frame is empty"):
+            pipe.collect(pipe.submit([raws[0], np.zeros((0, 4), np.float32)], iterations=3))
+        # and the pipeline is usable afterwards
+        steps, _ = pipe.collect(pipe.submit(raws, iterations=3))
+        assert len(steps[0][0]) == 3
+    finally:
+        pipe.close()
+    few = SequencePipeline(max_frames=2, max_points=131072, max_scans=32)
+    try:
+        with pytest.raises(PcpError, match="64 scan lines do not fit maxScans = 32"):
+            few.collect(few.submit(raws, iterations=3))
+    finally:
+        few.close()
+
+
+def test_raw_sequence_odometry_equals_the_float64_driver():
+    from pointcloudprocessing_amd.sequence import sequence_odometry_raw
+    raws = [_raw4(r) for r in kitti_sequence_raw()]
+    got = sequence_odometry_raw(raws, iterations=10, chunk=4)             # 11 pairs in runs of 4, 4, 3
+    want = odometry.sequence_odometry([lidar.frame_from_raw(r[:, :3]) for r in raws], iterations=10, batch_size=4)
+    for (R, t), (Rw, tw) in zip(got, want):
+        assert np.array_equal(R, Rw) and np.array_equal(t, tw)
