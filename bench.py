@@ -1,24 +1,28 @@
-"""Headline benchmark: ICP frame-pairs/s (and the NN queries/s inside them) on
-~120k-point KITTI-size scans.
+"""Headline benchmark: ICP frame-pairs/s (and the NN queries/s inside them) on ~120k-point KITTI scans.
 
     python bench.py --gpus N --steps K --warmup W
 
-Workload (the reference's point-to-plane registration of a KITTI-size frame pair; the
-golden-tiger.ply cloud its demo uses is not available, so the pair is built from a KITTI frame): a 64-ring 120k-point sweep registered
-against a rigidly moved, noise-perturbed copy of itself by point-to-plane ICP
-with ring normals, at most 10 iterations, stop at mean|dx| < 1e-6
-(PointcloudIcpContainer.full_pt2pl as UI.py:400 calls it).  One STEP = every
-rank registers its batch of --pairs independent frame pairs: per pair the
-kernel half of preparePointToPlane (unit vectors, normals, hint reset) and the
-whole device-resident iteration loop, all pairs of the rank batched: one kernel
-launch per iteration covers every pair (pcp_batch_icp_launch).  Inputs (target
-cloud, scan lines, float64 source cloud) are resident in HBM before the timed
-region starts.
-Pairs are independent, so ranks share nothing: weak scaling, no collective in
-the data path (torch.distributed only supplies the barrier and the max).
+Workload `sequence` (default): frame-to-frame odometry over real consecutive KITTI sweeps
+(2011_09_26 drive, frames 0000000000 ... 0000000011 of the reference's sample_data, held as fixtures;
+walked forwards and backwards so that every pair is a consecutive one).  One STEP = every rank registers
+a run of --pairs + 1 raw frames = --pairs consecutive pairs by point-to-plane ICP with ring normals,
+at most 10 iterations, stop at mean|dx| < 1e-6 (PointcloudIcpContainer.full_pt2pl as UI.py:400 calls
+it), starting from the raw velodyne records in page-locked HOST memory: the timed region holds the
+upload of every frame (copy stream, overlapped with the previous step's kernels), decode + ego filter
++ rotation, ring segmentation, unit vectors, ring bands, normals, the whole iteration loop of every
+pair and the fetch of the solved steps.  Nothing of a step is resident beforehand.
+Pairs are independent, so ranks share nothing: weak scaling, no collective in the data path
+(torch.distributed only supplies the barrier and the max).
+
+Workload `moved-copy` is the previous round's configs[1] substitute (frame 0 against rigidly moved +
+noise copies, inputs resident), kept for comparison.
+
+Extra objects on the line (N = 1 only): `nn` (stand-alone NearestNeighbourScan), `pt2pt20` (configs[0]),
+`voxel_sweep` (configs[2]), `single_pair` (latency of one registration).
 """
 import argparse
 import ctypes as C
+import glob
 import json
 import os
 import sys
@@ -29,19 +33,40 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from pointcloudprocessing_amd import MODE_PLANE, ComputeShader, IcpBatch, PointcloudIcpContainer, lidar  # noqa: E402
+from pointcloudprocessing_amd import (MODE_PLANE, ComputeShader, IcpBatch, PinnedFrames,  # noqa: E402
+                                      PointcloudIcpContainer, SequencePipeline, lidar)
 from pointcloudprocessing_amd._lib import check, f64p  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak
 MAX_ITER = 10
 TOL = 1e-6
+GOLD = os.path.join(ROOT, "tests", "golden")
 
 
-def base_cloud():
-    gold = os.path.join(ROOT, "tests", "golden", "kitti_pair.npz")
-    if os.path.exists(gold):
-        return lidar.frame_from_raw(np.load(gold)["raw0"]), "kitti 2011_09_26 frame 0000000000 (fixture)"
-    return lidar.synthetic_scan(0), "synthetic 64-ring sweep"
+# ----------------------------------------------------------------------------------- inputs
+def real_frames():
+    """The twelve raw sweeps (N, 4) float32; a synthetic drive of the same shape when the fixtures are absent."""
+    pair, seq = os.path.join(GOLD, "kitti_pair.npz"), os.path.join(GOLD, "kitti_seq.npz")
+    if os.path.exists(pair) and os.path.exists(seq):
+        g = np.load(pair)
+        raws = [g["raw0"], g["raw1"]] + lidar.unpack_raw_frames(np.load(seq))
+        name = "kitti 2011_09_26 frames 0000000000-0000000011 (fixtures), consecutive pairs"
+    else:
+        back = lidar.aligning_rotation().T
+        raws = [(back @ lidar.synthetic_scan(k, pose_t=np.array([0.0, 0.0, -0.33 * k])).T).T.astype(np.float32)
+                for k in range(12)]
+        name = "synthetic 64-ring drive, 0.33 m per sweep"
+    return [np.ascontiguousarray(np.column_stack([r, np.zeros(len(r), np.float32)]), dtype=np.float32) for r in raws], name
+
+
+def ping_pong(n, distinct, start):
+    """n frame indices walking 0 .. distinct-1 .. 0 .. from `start`: neighbours are always consecutive frames."""
+    period = 2 * (distinct - 1)
+    out = []
+    for j in range(start, start + n):
+        k = j % period
+        out.append(k if k < distinct else period - k)
+    return out
 
 
 def moved_copy(a, seed):
@@ -51,6 +76,102 @@ def moved_copy(a, seed):
     R = lidar.rotation_xyz(0.02 * s, -0.01 * s, 0.015 * s)
     t = np.array([0.05, -0.02, 0.03]) * s
     return (R @ a.T).T + t + rng.normal(0.0, 0.01, a.shape), R, t
+
+
+def traffic_for(workload, pairs, n_b):
+    """HBM bytes per launch of the dominant kernel from the counter passes (rocprofv3 --pmc FETCH_SIZE /
+    WRITE_SIZE, one pass each, which cannot run inside this process): their committed summary is quoted
+    when it was taken on this very workload, else None."""
+    for tf in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))[::-1]:
+        tr = json.load(open(tf))
+        if (tr.get("workload"), tr.get("pairs_per_launch")) == (workload, pairs) and abs(tr.get("n_b", 0) - n_b) < 2000:
+            return tr["fetch_bytes_per_launch"] + tr["write_bytes_per_launch"]
+    return None
+
+
+# ----------------------------------------------------------------------------------- workloads
+def run_sequence(args, rank, world, device, barrier):
+    raws, source = real_frames()
+    pinned = PinnedFrames(raws)
+    order = ping_pong(args.pairs + 1, len(raws), 3 * rank)
+    frames = [pinned[k] for k in order]
+    cap = 1 << 17
+    while cap < max(len(r) for r in raws):
+        cap <<= 1
+    pipe = SequencePipeline(args.pairs + 1, max_points=cap, device=device)
+
+    def run(steps):
+        last, pending = None, None
+        for _ in range(steps):
+            t = pipe.submit(frames, point_to_plane=True, iterations=MAX_ITER, tol=TOL)
+            if pending is not None:
+                last = pipe.collect(pending)
+            pending = t
+        if pending is not None:
+            last = pipe.collect(pending)
+        return last
+
+    run(args.warmup)
+    barrier()
+    t0 = time.perf_counter()
+    steps, n_pts = run(args.steps)
+    barrier()
+    elapsed = time.perf_counter() - t0
+
+    # what the timed steps computed, and a sanity check on it: a pair and the same pair walked backwards
+    # must be inverse motions, and the car moves a few decimetres per sweep
+    poses = pipe.poses(steps, True)
+    seen = {}
+    for p, (t, R) in enumerate(poses):
+        seen[(order[p], order[p + 1])] = (t, R)
+        step_len = np.linalg.norm(t)
+        if not (0.05 < step_len < 2.0) and not os.environ.get("PCP_BENCH_NOCHECK"):
+            raise SystemExit(f"INVALID: pair {order[p]}->{order[p + 1]} moved {step_len:.3f} m")
+    for (i, j), (t, R) in seen.items():
+        if (j, i) in seen and not os.environ.get("PCP_BENCH_NOCHECK"):
+            tb, Rb = seen[(j, i)]
+            if np.abs(R @ Rb - np.eye(3)).max() > 2e-3 or np.abs(R @ tb + t).max() > 3e-2:
+                raise SystemExit(f"INVALID: pairs {i}->{j} and {j}->{i} are not inverse motions")
+    iters = [len(dx) for dx, _ in steps]
+    n_b = int(np.mean(n_pts[1:]))
+    queries = float(sum(it * n for it, n in zip(iters, n_pts[1:]))) * world * args.steps
+
+    # roofline leg: the same steps once more, one at a time, with a HIP event before/after every fused
+    # NN + least-squares launch on the stream those launches run on
+    pipe.profile(True)
+    ls_ms, ls_launches, ls_points = 0.0, 0, 0
+    reps = max(1, min(args.steps, 5))
+    for _ in range(reps):
+        pipe.collect(pipe.submit(frames, point_to_plane=True, iterations=MAX_ITER, tol=TOL))
+        ms, n, pts = pipe.profile_read()
+        ls_ms, ls_launches, ls_points = ls_ms + ms, ls_launches + n, ls_points + pts
+    pipe.profile(False)
+    # algorithmic bytes of one launch = 32 B per source point it processed (16 B point + 8 B hint r/w + 8 B
+    # result) + the 32 B per target point (point + normal) each pair reads once, spread over its launches
+    alg_bytes = (32.0 * ls_points + 32.0 * float(sum(n_pts[:-1])) * reps) / max(ls_launches, 1)
+    avg_launch_s = ls_ms * 1e-3 / max(ls_launches, 1)
+
+    # latency of one pair from its raw bytes in host memory to its steps on the host, nothing else in flight
+    two = [pinned[0], pinned[1]]
+    lat = []
+    for _ in range(13):
+        c0 = time.perf_counter()
+        pipe.collect(pipe.submit(two, point_to_plane=True, iterations=MAX_ITER, tol=TOL))
+        lat.append(time.perf_counter() - c0)
+    raw_latency = float(np.median(lat[3:]) * 1e3)
+    pipe.close()
+    out = {
+        "value": args.pairs * world * args.steps / elapsed, "elapsed": elapsed, "queries": queries,
+        "data": "real sweeps: " + source, "n_a": int(np.mean(n_pts[:-1])), "n_b": n_b, "iters": float(np.mean(iters)),
+        "workload": "configs[3] on one GPU's share (the config the metric is quoted on): frame-to-frame point-to-plane ICP "
+                    "with ring normals over consecutive real KITTI sweeps, <= 10 iterations, from raw bytes in host memory "
+                    "(upload, decode, ring segmentation, normals, loop, fetch all inside the clock)",
+        "kernel": "k_ls_batch<plane> (fused ring-NN + JtJ/Jte + level-1 tree sum, all pairs of the step in one launch)",
+        "alg_bytes": alg_bytes, "avg_launch_s": avg_launch_s, "ls_launches": ls_launches,
+        "traffic": traffic_for("sequence", args.pairs, n_b), "raw_latency_ms": raw_latency,
+        "frames": (raws, pinned),
+    }
+    return out
 
 
 class Pair:
@@ -72,17 +193,179 @@ class Pair:
         return dx[:it.value], bool(cv.value)
 
 
+def run_moved_copy(args, rank, world, device, barrier):
+    """The previous round's workload: KITTI frame 0 against R*frame + t + N(0, 1 cm) copies of itself; target, scan
+    lines and float64 source resident before the timed region; one step = batched prepare + batched loop."""
+    raws, source = real_frames()
+    a = lidar.frame_from_raw(raws[0][:, :3])
+    lines = PointcloudIcpContainer(None).getScanLines(a, np.zeros(3))
+    pairs, truth = [], []
+    for p in range(args.pairs):
+        b, R, t = moved_copy(a, 1000 * rank + p)
+        pairs.append(Pair(device, a, lines, b))
+        truth.append((R, t))
+    batch = IcpBatch([p.cs for p in pairs])
+
+    def step():
+        batch.prepare(True)
+        batch.launch(MODE_PLANE, MAX_ITER, TOL, False)
+
+    for _ in range(args.warmup):
+        step()
+    batch.synchronize()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    batch.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    iters = []
+    for p, (R, t) in zip(pairs, truth):
+        dx, conv = p.result()
+        t_opt, R_opt = p.icp._replay(dx, len(dx) - 1 if conv else len(dx))
+        iters.append(len(dx))
+        err_R, err_t = np.abs(R_opt @ R - np.eye(3)).max(), np.abs(R_opt @ t - t_opt).max()
+        if not (err_R < 2e-3 and err_t < 2e-2) and not os.environ.get("PCP_BENCH_NOCHECK"):
+            raise SystemExit(f"INVALID: pair did not register (rotation err {err_R:.2e}, translation err {err_t:.2e})")
+    n_a, n_b = pairs[0].n_a, pairs[0].n_b
+    batch.profile(True)
+    ls_ms, ls_launches, ls_points = 0.0, 0, 0
+    reps = max(1, min(args.steps, 5))
+    for _ in range(reps):
+        step()
+        ms, n, pts = batch.profile_read()
+        ls_ms, ls_launches, ls_points = ls_ms + ms, ls_launches + n, ls_points + pts
+    batch.profile(False)
+    batch.close()
+    for p in pairs:
+        p.cs.cleanup()
+    return {
+        "value": args.pairs * world * args.steps / elapsed, "elapsed": elapsed,
+        "queries": float(sum(iters)) * n_b * world * args.steps,
+        "data": "synthetic motion + noise on frame 0 of: " + source, "n_a": n_a, "n_b": n_b, "iters": float(np.mean(iters)),
+        "workload": "configs[1] substitute: point-to-plane ICP with ring normals, <= 10 iterations, frame vs rigidly moved "
+                    "+ N(0,1cm) copy, inputs resident before the clock",
+        "kernel": "k_ls_batch<plane> (fused ring-NN + JtJ/Jte + level-1 tree sum, all pairs of the step in one launch)",
+        "alg_bytes": (32.0 * ls_points + 32.0 * n_a * args.pairs * reps) / max(ls_launches, 1),
+        "avg_launch_s": ls_ms * 1e-3 / max(ls_launches, 1), "ls_launches": ls_launches,
+        "traffic": traffic_for("moved-copy", args.pairs, n_b), "raw_latency_ms": None, "frames": (raws, None),
+    }
+
+
+# ----------------------------------------------------------------------------------- extras (rank 0, one GPU)
+def extras(raws, device):
+    """Driver-visible numbers for the other halves of the metric: stand-alone NN scan, configs[0], configs[2]."""
+    from pointcloudprocessing_amd import Voxelizer
+    from pointcloudprocessing_amd.cell_grid import CellGrid
+    out = {}
+    a, b = lidar.frame_from_raw(raws[0][:, :3]), lidar.frame_from_raw(raws[1][:, :3])
+    zero = np.zeros(3)
+    cs = ComputeShader(maxPointsPerCloud=200000, maxScans=100, device=device)
+    icp = PointcloudIcpContainer(cs)
+    ms = C.c_float(0)
+
+    # --- stand-alone NearestNeighbourScan (ComputeShader.py:731-759): first call searches all rings, later ones the hinted four
+    def nn_call():
+        c0 = time.perf_counter()
+        cs.dispatchNNS(b)
+        wall = time.perf_counter() - c0
+        check(cs._lib.pcp_nn_kernel_ms(cs._ctx, C.byref(ms)))
+        return wall, ms.value * 1e-3
+
+    first, hinted = [], []
+    for _ in range(5):
+        icp.prepareNNS(a, zero, b)
+        first.append(nn_call())
+        hinted.append(nn_call())
+    fw, fk = np.median([w for w, _ in first]), np.median([k for _, k in first])
+    hw, hk = np.median([w for w, _ in hinted]), np.median([k for _, k in hinted])
+    nn_bytes = 32.0 * len(b) + 16.0 * len(a)          # 16 B query + 8 B result + 8 B hint r/w per query, the target once
+    out["nn"] = {
+        "what": "prepareNNS + dispatchNNS on real pair 0 -> 1 (%d queries against %d points, 100 padded rings)" % (len(b), len(a)),
+        "all_rings": {"queries_per_s_kernel": len(b) / fk, "queries_per_s_call": len(b) / fw, "kernel_us": fk * 1e6,
+                      "call_ms": fw * 1e3},
+        "hinted": {"queries_per_s_kernel": len(b) / hk, "queries_per_s_call": len(b) / hw, "kernel_us": hk * 1e6,
+                   "call_ms": hw * 1e3},
+        "roofline": {"bound": "hbm", "kernel": "k_nn (hinted; one launch = one pair, so latency- not bandwidth-limited)",
+                     "achieved": nn_bytes / hk / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": nn_bytes / hk / 1e9 / HBM_PEAK_GBS, "traffic": None},
+        "note": "call = host buffers in, results on the host (2 MB upload + 1.5 MB read-back, PCIe inclusive)",
+    }
+
+    # --- configs[0]: consecutive pair, voxelize + NN + point-to-point ICP x 20
+    vox = Voxelizer(cs, None)
+    vox.init(0.5)
+    c0 = time.perf_counter()
+    vox.addPoints(a, None)
+    vox.addPoints(b, None)
+    cs.synchronize()
+    t_vox = time.perf_counter() - c0
+    voxels = vox.stored_voxels
+    vox.cleanup()
+    p2p = []
+    for _ in range(5):
+        c0 = time.perf_counter()
+        t_opt, R_opt = icp.full_pt2pt(a, b, zero, iterations=20)
+        p2p.append(time.perf_counter() - c0)
+    out["pt2pt20"] = {
+        "what": "configs[0]: real pair 0 -> 1, Voxelizer.addPoints of both sweeps at 0.5 m + prepareNNS/dispatchNNS + "
+                "full_pt2pt(iterations=20), host arrays in, pose out",
+        "voxelize_ms": t_vox * 1e3, "voxels": int(voxels), "nn_ms": (fw + hw) * 1e3 / 2,
+        "full_pt2pt_ms": float(np.median(p2p) * 1e3), "pairs_per_s": 1.0 / (t_vox + fw + float(np.median(p2p))),
+        "translation": [float(v) for v in t_opt],
+    }
+    cs.cleanup()
+
+    # --- configs[2]: 1 M synthetic points, voxel sizes 0.1 ... 2 m: voxelize + Morton sort + NN scan
+    sweeps = [lidar.synthetic_scan(s, rings=64, steps=1953) + np.array([0.5 * s, 0.0, 0.0]) for s in range(8)]
+    cloud = np.concatenate(sweeps)
+    rng = np.random.default_rng(1)
+    q = cloud + rng.normal(0, 0.05, cloud.shape)
+    cs = ComputeShader(maxPointsPerCloud=200000, device=device)
+    grid, rows = None, []
+    for size in (0.1, 0.2, 0.5, 1.0, 2.0):
+        best = None
+        for _ in range(2):
+            v = Voxelizer(cs, None)
+            v.init(size)
+            c0 = time.perf_counter()
+            for c in sweeps:
+                v.addPoints(c, None)
+            cs.synchronize()
+            dt = time.perf_counter() - c0
+            stored = v.stored_voxels
+            v.cleanup()
+            best = dt if best is None else min(best, dt)
+        if grid is None:
+            grid = CellGrid(cloud, cell=size, device=device)
+        else:
+            grid.rebuild(cloud, cell=size)
+        info = grid.info()
+        grid.query(q)
+        qms = min(grid.query(return_kernel_ms=True)[2] for _ in range(3))
+        rows.append({"voxel_m": size, "voxels": int(stored), "voxelize_ms": best * 1e3, "voxelize_mpts_per_s": len(cloud) / best / 1e6,
+                     "cells": int(info["cells"]), "morton_sort_ms": float(info["sort_ms"]), "sort_passes": int(info["sort_passes"]),
+                     "sort_gb_per_s": 24.0 * len(cloud) * info["sort_passes"] / (info["sort_ms"] * 1e-3) / 1e9 if info["sort_ms"] else None,
+                     "grid_build_ms": float(info["build_ms"]), "nn_ms": float(qms), "nn_queries_per_s": len(q) / (qms * 1e-3)})
+    grid.cleanup()
+    cs.cleanup()
+    out["voxel_sweep"] = {"what": "configs[2]: %d synthetic LiDAR-like points (8 sweeps): Voxelizer.addPoints per sweep, Morton radix "
+                                  "sort + cell table of the whole cloud, exact NN of the cloud jittered by 5 cm" % len(cloud),
+                          "rows": rows}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--pairs", type=int, default=64,
-                    help="independent frame pairs per GPU per step (64 = one GPU's share of a sequence "
-                         "replicated to 8 x 64 pairs)")
-    ap.add_argument("--streams", type=int, default=1,
-                    help="the pairs of a step are split into this many batches, each on a stream of its own")
+                    help="consecutive frame pairs per GPU per step (64 = one GPU's share of a 512-pair sequence on 8 GPUs)")
+    ap.add_argument("--workload", choices=("sequence", "moved-copy"), default="sequence")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true")
     args = ap.parse_args()
 
     import torch
@@ -101,122 +384,57 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", device))
         else:
             dist.init_process_group(backend)
-    local_rank = device
 
     def barrier():
-        for bt in batches:
-            bt.synchronize()
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
 
-    a, source = base_cloud()
-    icp_host = PointcloudIcpContainer(None)
-    lines = icp_host.getScanLines(a, np.zeros(3))
-    pairs, truth = [], []
-    for p in range(args.pairs):
-        b, R, t = moved_copy(a, 1000 * rank + p)
-        pairs.append(Pair(local_rank, a, lines, b))
-        truth.append((R, t))
-    per = -(-args.pairs // max(1, args.streams))
-    batches = [IcpBatch([p.cs for p in pairs[lo:lo + per]]) for lo in range(0, args.pairs, per)]
-
-    def step():
-        for bt in batches:
-            bt.prepare(True)                                  # unit vectors, ring bands, hints, normals
-        for bt in batches:
-            bt.launch(MODE_PLANE, MAX_ITER, TOL, False)       # the whole iteration loop of every pair
-
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    elapsed = time.perf_counter() - t0
+    res = (run_sequence if args.workload == "sequence" else run_moved_copy)(args, rank, world, device, barrier)
+    elapsed = res["elapsed"]
     if dist is not None:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-
-    # what the timed steps computed: iteration counts, and a sanity check that the
-    # registration recovered the inverse of the synthetic motion
-    iters = []
-    for p, (R, t) in zip(pairs, truth):
-        dx, conv = p.result()
-        applied = len(dx) - 1 if conv else len(dx)
-        t_opt, R_opt = p.icp._replay(dx, applied)
-        iters.append(len(dx))
-        err_R = np.abs(R_opt @ R - np.eye(3)).max()
-        err_t = np.abs(R_opt @ t - t_opt).max()
-        if not (err_R < 2e-3 and err_t < 2e-2) and not os.environ.get("PCP_BENCH_NOCHECK"):   # NOCHECK: kernel timing experiments only
-            raise SystemExit(f"INVALID: pair did not register (rotation err {err_R:.2e}, translation err {err_t:.2e})")
-    n_b = pairs[0].n_b
-    n_a = pairs[0].n_a
+    raws, pinned = res.pop("frames")
     total_pairs = args.pairs * world * args.steps
-    queries = float(sum(iters)) * n_b * world * args.steps       # every dispatch = n_b fused NN queries
 
-    # roofline leg: the same steps again with a HIP event before/after every fused
-    # NN + least-squares launch, on the stream those launches run on
-    for bt in batches:
-        bt.profile(True)
-    ls_ms, ls_launches, ls_points = 0.0, 0, 0
-    for _ in range(max(1, min(args.steps, 5))):
-        step()
-        for bt in batches:
-            ms, n, pts = bt.profile_read()
-            ls_ms += ms
-            ls_launches += n
-            ls_points += pts
-    for bt in batches:
-        bt.profile(False)
-    avg_iters = float(np.mean(iters))
-    # algorithmic bytes of one launch = 32 B per source point it processed + the 32 B per target
-    # point (point + normal) each pair reads once, spread over that pair's launches
-    alg_bytes = (32.0 * ls_points + 32.0 * n_a * args.pairs * max(1, min(args.steps, 5))) / max(ls_launches, 1)
-    avg_launch_s = ls_ms * 1e-3 / max(ls_launches, 1)
-    achieved = alg_bytes / avg_launch_s / 1e9
-
-    # HBM traffic per launch of that kernel comes from counter passes that cannot run inside this
-    # process (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, one pass each); their committed summary is
-    # quoted when it was taken on this very workload, else traffic stays null
-    traffic = None
-    import glob
-    for tf in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))[-1:]:
-        tr = json.load(open(tf))
-        if (tr.get("pairs_per_launch"), tr.get("n_a"), tr.get("n_b")) == (args.pairs, n_a, n_b):
-            traffic = tr["fetch_bytes_per_launch"] + tr["write_bytes_per_launch"]
-
-    # latency of ONE registration with nothing else in flight (not part of `value`): source upload, hint
-    # reset, the whole iteration loop and the fetch of the steps, target kept prepared on the device
-    for bt in batches:
-        bt.close()
-    batches = []
-    single = None
+    single, cpu, more = None, None, {}
     if rank == 0:
-        b0 = moved_copy(a, 1000 * rank)[0]
+        # one registration alone on the GPU, target kept prepared: upload of the 3 MB float64 source, loop, fetch
+        a, b = lidar.frame_from_raw(raws[0][:, :3]), lidar.frame_from_raw(raws[1][:, :3])
+        cs = ComputeShader(maxPointsPerCloud=max(len(a), len(b)), maxScans=100, device=device)
+        PointcloudIcpContainer(cs).preparePointToPlane(a, np.zeros(3), b)
         times = []
         for _ in range(13):
             c0 = time.perf_counter()
-            dx0, _, _, _ = pairs[0].cs.icpRun(b0, MODE_PLANE, MAX_ITER, tol=TOL)
+            dx0, _, _, _ = cs.icpRun(b, MODE_PLANE, MAX_ITER, tol=TOL)
             times.append(time.perf_counter() - c0)
+        cs.cleanup()
         single = {"ms": float(np.median(times[3:]) * 1e3), "iterations": int(len(dx0)),
-                  "what": "one pair alone on the GPU: upload of the 3 MB source, the iteration loop, fetch of the steps"}
-
-    cpu = None
+                  "what": "real pair 0 -> 1 alone on the GPU, target prepared: upload of the 3 MB float64 source, the loop, fetch",
+                  "from_raw_bytes_ms": res["raw_latency_ms"],
+                  "from_raw_bytes_what": "the same pair from its two raw records in host memory: upload, decode, rings, normals, loop, fetch"}
+    if rank == 0 and world == 1 and not args.no_extras:
+        more = extras(raws, device)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import np_oracle as O
-        sample = [moved_copy(a, p)[0] for p in range(2)]
+        sample = [(0, 1), (1, 2)]
         c0 = time.perf_counter()
-        for b0 in sample:
-            O.full_pt2pl(a, b0, np.zeros(3), iterations=MAX_ITER)
+        for i, j in sample:
+            fa, fb = lidar.frame_from_raw(raws[i][:, :3]), lidar.frame_from_raw(raws[j][:, :3])
+            if args.workload == "moved-copy":
+                fb = moved_copy(fa, j)[0]
+            O.full_pt2pl(fa, fb, np.zeros(3), iterations=MAX_ITER)
         cpu_s = time.perf_counter() - c0
         cpu = {"value": len(sample) / cpu_s, "unit": "frame-pairs/s", "cores": 1, "kind": "port",
-               "sample": "%d frame pairs of the same workload (pairs 0 and 1 of rank 0), NumPy restatement of the "
-                         "same algorithm, single thread; host has %d logical cpus" % (len(sample), os.cpu_count() or 0)}
+               "sample": "%d frame pairs of the same workload (pairs 0->1 and 1->2: decode, scan lines, normals, loop), NumPy "
+                         "restatement of the same algorithm, single thread; host has %d logical cpus" % (len(sample), os.cpu_count() or 0)}
+    if pinned is not None:
+        pinned.close()
 
     if rank == 0:
+        achieved = res["alg_bytes"] / res["avg_launch_s"] / 1e9 if res["avg_launch_s"] else 0.0
         out = {
             "metric": "ICP frame-pairs/s (120k-pt KITTI scans, NN queries/s alongside)",
             "value": total_pairs / elapsed,
@@ -229,26 +447,21 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "synthetic motion + noise on " + source,
-            "nn_queries_per_s": queries / elapsed,
-            "config": {"workload": "configs[1] substitute: point-to-plane ICP with ring normals, <=10 iterations, "
-                                   "frame vs rigidly moved + N(0,1cm) copy",
-                       "pairs_per_gpu_per_step": args.pairs, "n_a": n_a, "n_b": n_b,
-                       "iterations_per_pair": avg_iters, "parallelism": "independent pairs per GPU, batched launches"},
-            "roofline": {"bound": "hbm", "kernel": "k_ls_batch<plane> (fused ring-NN + JtJ/Jte + level-1 tree sum, "
-                                                   "all pairs of the step in one launch)",
-                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "avg_launch_us": avg_launch_s * 1e6, "launches_timed": ls_launches,
-                         "algorithmic_bytes_per_launch": alg_bytes},
+            "data": res["data"],
+            "nn_queries_per_s": res["queries"] / elapsed,
+            "config": {"workload": res["workload"], "pairs_per_gpu_per_step": args.pairs, "n_a": res["n_a"], "n_b": res["n_b"],
+                       "iterations_per_pair": res["iters"], "parallelism": "independent pairs per GPU, batched launches"},
+            "roofline": {"bound": "hbm", "kernel": res["kernel"], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": res["traffic"],
+                         "avg_launch_us": res["avg_launch_s"] * 1e6, "launches_timed": res["ls_launches"],
+                         "algorithmic_bytes_per_launch": res["alg_bytes"],
+                         "limited_by": "not HBM: dependent 16-byte gathers served by L1/L2 (vector-memory address path ~70 % busy, "
+                                       "vector ALU ~75 % busy, waves wait ~70 % of their life; counters under profiles/)"},
             "cpu_baseline": cpu,
             "single_pair": single,
         }
+        out.update(more)
         print(json.dumps(out))
-    for bt in batches:
-        bt.close()
-    for p in pairs:
-        p.cs.cleanup()
     if dist is not None:
         dist.destroy_process_group()
 

@@ -73,6 +73,10 @@ int pcp_normals(pcp_ctx* ctx, float* out_normals /* n_a x 4 */);
 int pcp_nn(pcp_ctx* ctx, const float* b_xyzw, int n_b,
            uint32_t* idx, float* dist2, float* hint_out);
 
+/* Device time (ms, HIP events on the context's stream) of the search kernels of the last pcp_nn call,
+ * without its upload and read-back. */
+int pcp_nn_kernel_ms(pcp_ctx* ctx, float* ms);
+
 /* dispatchLS (:517-529) = LeastSquaresPoint.glsl + the ParalellHBSum tree;
  * hb receives the summed 8x8 tile (H = hb[:6,:6], b = hb[:6,6]).
  * debug != 0 selects identity correspondences (debug_info.x >= 1). */
@@ -405,6 +409,12 @@ int pcp_seq_submit(pcp_seq* seq, const float* const* raw_xyzi, const int* n_raw,
  * a scan line, an empty source, singular normal equations. */
 int pcp_seq_collect(pcp_seq* seq, int ticket, float* dx_trace, int dx_stride_iters, int* iters, int* converged,
                     int* n_points);
+/* As pcp_batch_profile_enable / pcp_batch_profile_read: HIP events on the compute stream around every fused
+ * NN + least-squares launch of the submissions made while enabled; read (after collecting) the summed
+ * duration of the last collected submission's launches that did work, their number and the source points
+ * they processed. */
+int pcp_seq_profile_enable(pcp_seq* seq, int on);
+int pcp_seq_profile_read(pcp_seq* seq, float* ls_ms, int* launches, long long* points);
 /* Page-locked host memory for buffers handed to pcp_seq_submit (hipHostMalloc / hipHostFree). */
 int pcp_host_alloc(size_t bytes, void** out);
 int pcp_host_free(void* p);

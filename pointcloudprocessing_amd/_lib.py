@@ -38,6 +38,7 @@ SIGNATURES = {
     "pcp_reset_hints": (C.c_int, [_ctx]),
     "pcp_normals": (C.c_int, [_ctx, _f32p]),
     "pcp_nn": (C.c_int, [_ctx, _f32p, C.c_int, _u32p, _f32p, _f32p]),
+    "pcp_nn_kernel_ms": (C.c_int, [_ctx, _f32p]),
     "pcp_ls_point": (C.c_int, [_ctx, _f32p, C.c_int, C.c_int, _f32p]),
     "pcp_ls_plane": (C.c_int, [_ctx, _f32p, C.c_int, _f32p]),
     "pcp_ls_tiles": (C.c_int, [_ctx, _f32p, C.c_int, C.c_int, C.c_int, _f32p]),
@@ -115,6 +116,8 @@ SIGNATURES = {
     "pcp_seq_submit": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), _i32p, C.c_int, C.c_float, _f64p, _f64p, C.c_int, C.c_int,
                                  C.c_float, C.c_int, _i32p]),
     "pcp_seq_collect": (C.c_int, [C.c_void_p, C.c_int, _f32p, C.c_int, _i32p, _i32p, _i32p]),
+    "pcp_seq_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
+    "pcp_seq_profile_read": (C.c_int, [C.c_void_p, _f32p, _i32p, C.POINTER(C.c_longlong)]),
     "pcp_host_alloc": (C.c_int, [C.c_size_t, C.POINTER(C.c_void_p)]),
     "pcp_host_free": (C.c_int, [C.c_void_p]),
     "pcp_ring_stats": (C.c_int, [_ctx, _f32p]),

@@ -42,6 +42,8 @@ struct pcp_ctx {
     bool have_target = false, have_normals = false;
     int run_mode = 0, run_max_iter = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t nn_ev0 = nullptr, nn_ev1 = nullptr;   // around the kernels of the last pcp_nn (created on first use)
+    bool nn_timed = false;
     bool profile = false;                 // bracket every LS launch of the loop with events
     std::vector<hipEvent_t> prof_events;  // pairs (before, after), created on demand
     int prof_used = 0;

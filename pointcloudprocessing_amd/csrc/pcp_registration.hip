@@ -838,6 +838,8 @@ int pcp_destroy(pcp_ctx* c) {
         if (p) (void)hipFree(p);
     if (c->vox) pcp_voxel_state_free(c->vox);
     for (hipEvent_t ev : c->prof_events) (void)hipEventDestroy(ev);
+    if (c->nn_ev0) (void)hipEventDestroy(c->nn_ev0);
+    if (c->nn_ev1) (void)hipEventDestroy(c->nn_ev1);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -944,15 +946,31 @@ int pcp_nn(pcp_ctx* c, const float* b_xyzw, int n_b, uint32_t* idx, float* dist2
     if (int e = use(c)) return e;
     if (!idx || !dist2) return pcp_fail("null output");
     if (int e = upload_b32(c, b_xyzw, n_b)) return e;
+    if (!c->nn_ev0) {
+        PCP_CHECK(hipEventCreate(&c->nn_ev0));
+        PCP_CHECK(hipEventCreate(&c->nn_ev1));
+    }
+    PCP_CHECK(hipEventRecord(c->nn_ev0, c->stream));
     if (int e = launch_first_rings<false>(c)) return e;          // queries still without a hint: their ring, found by 8 lanes each
     hipLaunchKernelGGL(k_nn, dim3(cdiv(n_b, PCP_BLOCK)), dim3(PCP_BLOCK), scan_smem(c), c->stream, c->a, c->ua, c->scan, c->ring_stat, c->ring_bins,
                        c->n_a, c->n_scans, c->n_scans_search, c->origin, c->b32, n_b, c->hint, c->nn_idx, c->nn_dist);
     PCP_CHECK(hipGetLastError());
+    PCP_CHECK(hipEventRecord(c->nn_ev1, c->stream));
+    c->nn_timed = true;
     PCP_CHECK(hipMemcpyAsync(idx, c->nn_idx, (size_t)n_b * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
     PCP_CHECK(hipMemcpyAsync(dist2, c->nn_dist, (size_t)n_b * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     if (hint_out)
         PCP_CHECK(hipMemcpyAsync(hint_out, c->hint, (size_t)n_b * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     PCP_CHECK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int pcp_nn_kernel_ms(pcp_ctx* c, float* ms) {
+    if (int e = use(c)) return e;
+    if (!ms) return pcp_fail("null output");
+    if (!c->nn_timed) return pcp_fail("no pcp_nn call to report on");
+    PCP_CHECK(hipEventSynchronize(c->nn_ev1));
+    PCP_CHECK(hipEventElapsedTime(ms, c->nn_ev0, c->nn_ev1));
     return 0;
 }
 

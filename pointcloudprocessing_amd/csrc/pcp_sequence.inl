@@ -253,6 +253,11 @@ struct pcp_seq {
     int in_flight[2] = {0, 0};                  // pairs of the submission in each result slot, 0 = free
     int ticket_of[2] = {-1, -1}, iters[2] = {0, 0};
     long long submitted = 0;
+    bool profile = false;                       // bracket every fused NN + least-squares launch with events
+    std::vector<hipEvent_t> prof_events;
+    int prof_launches = 0;                      // launches bracketed by the last submission
+    int last_longest = 0;                       // most iterations any pair of the last collected run made
+    long long last_points = 0;                  // source points its launches processed
 };
 
 extern "C" {
@@ -274,6 +279,7 @@ int pcp_seq_destroy(pcp_seq* s) {
         if (s->rec_host[k]) (void)hipHostFree(s->rec_host[k]);
         if (s->finished[k]) (void)hipEventDestroy(s->finished[k]);
     }
+    for (hipEvent_t ev : s->prof_events) (void)hipEventDestroy(ev);
     if (s->uploaded) (void)hipEventDestroy(s->uploaded);
     if (s->decoded) (void)hipEventDestroy(s->decoded);
     if (s->copy) (void)hipStreamDestroy(s->copy);
@@ -437,9 +443,22 @@ int pcp_seq_submit(pcp_seq* s, const float* const* raw_xyzi, const int* n_raw, i
     PCP_CHECK(hipGetLastError());
     // the iteration loops of all pairs; the registered clouds are not needed, so the last step is not applied
     const dim3 grid(cdiv(s->max_points, PCP_BLOCK), P), block(PCP_BLOCK);
+    s->prof_launches = 0;
     for (int it = 0; it < max_iter; ++it) {
+        if (s->profile) {
+            while ((int)s->prof_events.size() < 2 * (it + 1)) {
+                hipEvent_t ev;
+                PCP_CHECK(hipEventCreate(&ev));
+                s->prof_events.push_back(ev);
+            }
+            PCP_CHECK(hipEventRecord(s->prof_events[2 * it], q));
+        }
         if (mode == PCP_MODE_POINT) hipLaunchKernelGGL((k_ls_batch<PCP_MODE_POINT>), grid, block, sm, q, s->ls_dev);
         else hipLaunchKernelGGL((k_ls_batch<PCP_MODE_PLANE>), grid, block, sm, q, s->ls_dev);
+        if (s->profile) {
+            PCP_CHECK(hipEventRecord(s->prof_events[2 * it + 1], q));
+            s->prof_launches = it + 1;
+        }
         hipLaunchKernelGGL(k_finish_batch, dim3(P), dim3(1024), 0, q, s->fin_dev, mode, max_iter, tol, full_iter);
     }
     PCP_CHECK(hipGetLastError());
@@ -467,8 +486,14 @@ int pcp_seq_collect(pcp_seq* s, int ticket, float* dx_trace, int dx_stride_iters
     const SeqRecord* rec = s->rec_host[slot];
     if (dx_trace && dx_stride_iters < s->iters[slot]) return pcp_fail("dx_trace holds %d steps per pair, the run made up to %d", dx_stride_iters, s->iters[slot]);
     int bad = -1;
+    s->last_longest = 0;
+    s->last_points = 0;
     for (int p = 0; p < P; ++p) {
         const SeqRecord& r = rec[p];
+        if (!r.flags) {
+            s->last_longest = r.iters > s->last_longest ? r.iters : s->last_longest;
+            s->last_points += (long long)r.iters * r.n_b;
+        }
         if (iters) iters[p] = r.iters;
         if (converged) converged[p] = r.converged;
         if (n_points) { n_points[p] = r.n_a; n_points[p + 1] = r.n_b; }
@@ -482,6 +507,32 @@ int pcp_seq_collect(pcp_seq* s, int ticket, float* dx_trace, int dx_stride_iters
         if (r.flags & 4) return pcp_fail("pair %d: the source frame is empty", bad);
         return pcp_fail("pair %d: singular normal equations at iteration %d", bad, r.iters - 1);
     }
+    return 0;
+}
+
+int pcp_seq_profile_enable(pcp_seq* s, int on) {
+    if (!s) return pcp_fail("null sequence");
+    s->profile = on != 0;
+    return 0;
+}
+
+int pcp_seq_profile_read(pcp_seq* s, float* ls_ms, int* launches, long long* points) {
+    if (!s) return pcp_fail("null sequence");
+    if (!ls_ms || !launches || !points) return pcp_fail("null output");
+    if (s->in_flight[0] || s->in_flight[1]) return pcp_fail("collect the submissions in flight first");
+    PCP_CHECK(hipSetDevice(s->device));
+    PCP_CHECK(hipStreamSynchronize(s->compute));
+    // launches after every pair has finished return at once: only those that did work count
+    const int n = s->last_longest < s->prof_launches ? s->last_longest : s->prof_launches;
+    float total = 0.f;
+    for (int i = 0; i < n; ++i) {
+        float ms = 0.f;
+        PCP_CHECK(hipEventElapsedTime(&ms, s->prof_events[2 * i], s->prof_events[2 * i + 1]));
+        total += ms;
+    }
+    *ls_ms = total;
+    *launches = n;
+    *points = s->last_points;
     return 0;
 }
 

@@ -105,6 +105,16 @@ class SequencePipeline:
             out.append(self._icp._replay(dx, applied))
         return out
 
+    def profile(self, on):
+        check(self._lib.pcp_seq_profile_enable(self._seq, int(on)))
+
+    def profile_read(self):
+        """(summed ms of the fused NN + least-squares launches of the last collected run that did work, their
+        count, source points they processed); HIP events on the stream the launches ran on."""
+        ms, n, pts = C.c_float(0), C.c_int(0), C.c_longlong(0)
+        check(self._lib.pcp_seq_profile_read(self._seq, C.byref(ms), C.byref(n), C.byref(pts)))
+        return ms.value, n.value, pts.value
+
     def close(self):
         if self._seq:
             self._lib.pcp_seq_destroy(self._seq)
