@@ -17,6 +17,13 @@
  *     ComputeShader.py:26)
  *   - points are float32 rows of 4 (x, y, z, w); scan lines are uint32 rows of
  *     4 (begin, end_inclusive, 1, 1) exactly as ComputeShader uploads them
+ *   - calls that return results to host pointers wait for them.  Calls that only take host input
+ *     (pcp_set_target, pcp_upload_source, pcp_upload_source_soa; the b_xyzw argument of a call that
+ *     fails after its upload) enqueue the copy and return: the caller's buffer must stay valid and
+ *     unchanged until the next call on that context that waits (pcp_synchronize, pcp_icp_fetch,
+ *     pcp_batch_synchronize, any call that returns results)
+ *   - a context adopted by a batch (pcp_batch_create) may be destroyed before the batch: pcp_destroy
+ *     then drains the batch's stream and takes the context out of the batch
  */
 #ifndef PCP_H
 #define PCP_H

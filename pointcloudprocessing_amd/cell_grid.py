@@ -125,7 +125,12 @@ class CellGrid:
         idx = np.zeros(self.m, dtype=np.int64)
         dist = np.zeros(self.m, dtype=np.float64)
         ms = C.c_float(0)
-        bound = float(distance_upper_bound) if np.isfinite(distance_upper_bound) else 0.0
+        bound = float(distance_upper_bound)
+        if np.isnan(bound) or (np.isfinite(bound) and bound <= 0.0) or bound == -np.inf:
+            # nothing is strictly nearer than a bound <= 0: all misses, as scipy answers (0.0 is the library's "no bound")
+            dist[:], idx[:] = np.inf, self.n
+            return (dist, idx, 0.0) if return_kernel_ms else (dist, idx)
+        bound = bound if np.isfinite(bound) else 0.0
         check(self._lib.pcp_grid_query_resident(self._g, bound, _i64p(idx), f64p(dist), C.byref(ms)))
         idx[idx < 0] = self.n
         return (dist, idx, ms.value) if return_kernel_ms else (dist, idx)

@@ -385,11 +385,13 @@ class IcpBatch:
 
     def upload_sources(self, clouds):
         """float64 (N, 3) source cloud per pair (hints are reset by prepare())."""
+        keep = []
         for c, pts in zip(self.computes, clouds):
             b = np.ascontiguousarray(np.asarray(pts)[:, :3], dtype=np.float64)
             check(self._lib.pcp_upload_source(c._ctx, f64p(b), len(b)))
-            check(self._lib.pcp_synchronize(c._ctx))
+            keep.append(b)                       # the copies are in flight: the arrays live until the one wait below
             c._n_source = len(b)
+        self.synchronize()
 
     def prepare(self, with_normals):
         check(self._lib.pcp_batch_prepare(self._batch, int(with_normals)))

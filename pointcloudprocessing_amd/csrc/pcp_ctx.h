@@ -30,6 +30,9 @@ struct pcp_ctx {
     float *hint = nullptr, *nn_dist = nullptr;
     uint32_t* nn_idx = nullptr;
     int2* scan = nullptr;
+    int2* scan_host = nullptr;     // page-locked staging of the scan-line table (max_scans rows)
+    hipEvent_t scan_copied = nullptr;   // recorded behind the copy out of scan_host
+    struct pcp_batch* batch = nullptr;  // the batch that has adopted this context, if any
     float4* ring_stat = nullptr;   // per ring: (sin, cos) of lowest and highest elevation
     float4* ring_bins = nullptr;   // the same per ring and azimuth bin (PCP_AZ_BINS per ring)
     float *partials = nullptr, *lvl0 = nullptr, *lvl1 = nullptr;

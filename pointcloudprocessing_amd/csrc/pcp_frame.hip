@@ -112,6 +112,8 @@ struct pcp_frame {
 
 extern "C" {
 
+int pcp_frame_destroy(pcp_frame* f);
+
 int pcp_frame_create(int device, size_t max_points, pcp_frame** out) {
     if (!out) return pcp_fail("out is null");
     *out = nullptr;
@@ -123,26 +125,32 @@ int pcp_frame_create(int device, size_t max_points, pcp_frame** out) {
     pcp_frame* f = new pcp_frame();
     f->device = device;
     f->cap = max_points;
-    PCP_CHECK(hipStreamCreateWithFlags(&f->stream, hipStreamNonBlocking));
-    PCP_CHECK(hipMalloc(&f->raw, max_points * 16));
-    PCP_CHECK(hipMalloc(&f->xyz, max_points * 24));
-    PCP_CHECK(hipMalloc(&f->intensity, max_points * 4));
-    PCP_CHECK(hipMalloc(&f->xyzw32, max_points * 16));
-    PCP_CHECK(hipMalloc(&f->ends, max_points * 4));
-    PCP_CHECK(hipMalloc(&f->counts, (max_points / FR_TILE + 2) * 4));
-    PCP_CHECK(hipMalloc(&f->rt, 12 * 8));
+    hipError_t e = hipStreamCreateWithFlags(&f->stream, hipStreamNonBlocking);
+    auto A = [&](void** p, size_t bytes) { if (e == hipSuccess) e = hipMalloc(p, bytes); };
+    A((void**)&f->raw, max_points * 16);
+    A((void**)&f->xyz, max_points * 24);
+    A((void**)&f->intensity, max_points * 4);
+    A((void**)&f->xyzw32, max_points * 16);
+    A((void**)&f->ends, max_points * 4);
+    A((void**)&f->counts, (max_points / FR_TILE + 2) * 4);
+    A((void**)&f->rt, 12 * 8);
+    if (e != hipSuccess) {
+        pcp_fail("pcp_frame_create: %s", hipGetErrorString(e));
+        pcp_frame_destroy(f);          // frees what was allocated
+        return 1;
+    }
     *out = f;
     return 0;
 }
 
 int pcp_frame_destroy(pcp_frame* f) {
     if (!f) return 0;
-    PCP_CHECK(hipSetDevice(f->device));
-    PCP_CHECK(hipStreamSynchronize(f->stream));
+    (void)hipSetDevice(f->device);
+    if (f->stream) (void)hipStreamSynchronize(f->stream);
     for (void* p : {(void*)f->raw, (void*)f->xyz, (void*)f->intensity, (void*)f->xyzw32, (void*)f->ends,
                     (void*)f->counts, (void*)f->rt})
-        if (p) PCP_CHECK(hipFree(p));
-    PCP_CHECK(hipStreamDestroy(f->stream));
+        if (p) (void)hipFree(p);
+    if (f->stream) (void)hipStreamDestroy(f->stream);
     delete f;
     return 0;
 }

@@ -1064,15 +1064,23 @@ int reserve_source(pcp_grid* g, size_t m) {
     if (free_source(g)) return 1;
     const size_t cap = std::max<size_t>(m, 1024);
     const size_t waves = (cap + 63) / 64, l1 = (waves + 63) / 64 + 1;
-    PCP_CHECK(hipMalloc(&g->src_in, cap * 24));
-    PCP_CHECK(hipMalloc(&g->src, cap * 24));
-    PCP_CHECK(hipMalloc(&g->nn_d, cap * 8));
-    PCP_CHECK(hipMalloc(&g->nn_idx, cap * 8));
-    PCP_CHECK(hipMalloc(&g->nn_pos, cap * 4));
-    PCP_CHECK(hipMalloc(&g->sel, cap));
-    PCP_CHECK(hipMalloc(&g->partials, waves * PCP_PSTRIDE * 4));
-    PCP_CHECK(hipMalloc(&g->lvl0, l1 * PCP_PSTRIDE * 4));
-    PCP_CHECK(hipMalloc(&g->lvl1, l1 * PCP_PSTRIDE * 4));
+    hipError_t e = hipSuccess;
+    auto A = [&](void** p, size_t bytes) { if (e == hipSuccess) e = hipMalloc(p, bytes); };
+    A((void**)&g->src_in, cap * 24);
+    A((void**)&g->src, cap * 24);
+    A((void**)&g->nn_d, cap * 8);
+    A((void**)&g->nn_idx, cap * 8);
+    A((void**)&g->nn_pos, cap * 4);
+    A((void**)&g->sel, cap);
+    A((void**)&g->partials, waves * PCP_PSTRIDE * 4);
+    A((void**)&g->lvl0, l1 * PCP_PSTRIDE * 4);
+    A((void**)&g->lvl1, l1 * PCP_PSTRIDE * 4);
+    if (e != hipSuccess) {          // leave the grid without a source rather than with half of one
+        pcp_fail("source buffers for %zu points: %s", cap, hipGetErrorString(e));
+        (void)free_source(g);
+        g->m = 0;
+        return 1;
+    }
     g->m_cap = cap;
     return 0;
 }

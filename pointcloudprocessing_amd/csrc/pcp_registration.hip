@@ -816,6 +816,8 @@ int pcp_create(int device, int max_points, int max_scans, pcp_ctx** out) {
     A((void**)&c->dx_trace, (size_t)pcp_ctx::max_iter_cap * 6 * sizeof(float));
     A((void**)&c->state, sizeof(IcpState));
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipHostMalloc((void**)&c->scan_host, (size_t)max_scans * sizeof(int2));
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->scan_copied, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreate(&c->ev0);
     if (e == hipSuccess) e = hipEventCreate(&c->ev1);
     if (e != hipSuccess) {
@@ -828,9 +830,15 @@ int pcp_create(int device, int max_points, int max_scans, pcp_ctx** out) {
     return 0;
 }
 
+static void batch_forget(pcp_batch* b, pcp_ctx* c);
+
 int pcp_destroy(pcp_ctx* c) {
     if (!c) return 0;
     (void)hipSetDevice(c->device);
+    if (c->batch) {               // destroyed before the batch that adopted it: drain that stream, leave the batch
+        (void)hipStreamSynchronize(c->stream);
+        batch_forget(c->batch, c);
+    }
     if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
     void* bufs[] = {c->a, c->ua, c->normals, c->b32, c->b_in, c->b64, c->hint, c->nn_dist, c->nn_idx, c->scan, c->ring_stat, c->ring_bins,
                     c->partials, c->lvl0, c->lvl1, c->hb_trace, c->dx_trace, c->state, c->tiles, c->tiles2};
@@ -838,6 +846,8 @@ int pcp_destroy(pcp_ctx* c) {
         if (p) (void)hipFree(p);
     if (c->vox) pcp_voxel_state_free(c->vox);
     for (hipEvent_t ev : c->prof_events) (void)hipEventDestroy(ev);
+    if (c->scan_host) (void)hipHostFree(c->scan_host);
+    if (c->scan_copied) (void)hipEventDestroy(c->scan_copied);
     if (c->nn_ev0) (void)hipEventDestroy(c->nn_ev0);
     if (c->nn_ev1) (void)hipEventDestroy(c->nn_ev1);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -849,6 +859,7 @@ int pcp_destroy(pcp_ctx* c) {
 
 int pcp_set_stream(pcp_ctx* c, void* hip_stream) {
     if (!c) return pcp_fail("null context");
+    if (c->batch) return pcp_fail("the context runs on its batch's stream until pcp_batch_destroy");
     c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
     return 0;
 }
@@ -905,18 +916,21 @@ static int set_target_impl(pcp_ctx* c, const float* a_xyzw, int n_a, const uint3
     // the reference overflows its scan-line SSBO here and re-raises the GL error (ComputeShader.py:506-512)
     if (n_scans < 1 || n_scans > c->max_scans)
         return pcp_fail("%d scan lines do not fit maxScans = %d", n_scans, c->max_scans);
-    std::vector<int2> lines((size_t)n_scans);
     for (int i = 0; i < n_scans; ++i) {
         const uint32_t b = scan_lines[4 * i + 0], e = scan_lines[4 * i + 1];
         if (b > e || e >= (uint32_t)n_a)
             return pcp_fail("scan line %d = (%u, %u) outside a cloud of %d points", i, b, e, n_a);
-        lines[i] = make_int2((int)b, (int)e);
     }
+    // The table goes through a page-locked buffer the context owns, so the call need not wait for the copy;
+    // only a second upload while the first is still in flight waits (for that copy alone).
+    PCP_CHECK(hipEventSynchronize(c->scan_copied));
+    int2* lines = c->scan_host;
+    for (int i = 0; i < n_scans; ++i) lines[i] = make_int2((int)scan_lines[4 * i + 0], (int)scan_lines[4 * i + 1]);
     c->have_target = false;
     c->have_normals = false;
     PCP_CHECK(hipMemcpyAsync(c->a, a_xyzw, (size_t)n_a * sizeof(float4), kind, c->stream));
-    PCP_CHECK(hipMemcpyAsync(c->scan, lines.data(), lines.size() * sizeof(int2), hipMemcpyHostToDevice, c->stream));
-    PCP_CHECK(hipStreamSynchronize(c->stream));   // `lines` dies with this frame
+    PCP_CHECK(hipMemcpyAsync(c->scan, lines, (size_t)n_scans * sizeof(int2), hipMemcpyHostToDevice, c->stream));
+    PCP_CHECK(hipEventRecord(c->scan_copied, c->stream));
     c->origin = make_float4(origin4[0], origin4[1], origin4[2], origin4[3]);
     c->n_a = n_a;
     c->n_scans = n_scans;
@@ -1195,11 +1209,19 @@ struct pcp_batch {
     int run_max_iter = 0;
 };
 
+static void batch_forget(pcp_batch* b, pcp_ctx* c) {
+    for (size_t i = 0; i < b->ctxs.size(); ++i)
+        if (b->ctxs[i] == c) { b->ctxs.erase(b->ctxs.begin() + (long)i); break; }
+    b->ls_sent.clear(); b->fin_sent.clear(); b->prep_sent.clear();      // the descriptor arrays are rebuilt on the next launch
+    c->batch = nullptr;
+    c->stream = c->own_stream;
+}
+
 int pcp_batch_destroy(pcp_batch* b) {
     if (!b) return 0;
     (void)hipSetDevice(b->device);
     if (b->stream) (void)hipStreamSynchronize(b->stream);
-    for (pcp_ctx* c : b->ctxs) c->stream = c->own_stream;
+    for (pcp_ctx* c : b->ctxs) { c->stream = c->own_stream; c->batch = nullptr; }
     for (hipEvent_t ev : b->prof_events) (void)hipEventDestroy(ev);
     if (b->ls_host) (void)hipHostFree(b->ls_host);
     if (b->fin_host) (void)hipHostFree(b->fin_host);
@@ -1219,6 +1241,7 @@ int pcp_batch_create(pcp_ctx** ctxs, int n, pcp_batch** out) {
     for (int i = 0; i < n; ++i) {
         if (!ctxs[i]) return pcp_fail("null context in batch");
         if (ctxs[i]->device != ctxs[0]->device) return pcp_fail("all contexts of a batch must live on one device");
+        if (ctxs[i]->batch) return pcp_fail("context %d already belongs to a batch", i);
         for (int j = 0; j < i; ++j)
             if (ctxs[j] == ctxs[i]) return pcp_fail("context listed twice in a batch");
     }
@@ -1245,6 +1268,7 @@ int pcp_batch_create(pcp_ctx** ctxs, int n, pcp_batch** out) {
             return 1;
         }
         ctxs[i]->stream = b->stream;
+        ctxs[i]->batch = b;
         b->ctxs.push_back(ctxs[i]);
     }
     *out = b;
@@ -1255,6 +1279,7 @@ int pcp_batch_prepare(pcp_batch* b, int with_normals) {
     if (!b) return pcp_fail("null batch");
     PCP_CHECK(hipSetDevice(b->device));
     const int n = (int)b->ctxs.size();
+    if (n == 0) return pcp_fail("the batch holds no context any more");
     int max_na = 0, max_pts = 0, max_scans = 0;
     std::vector<PrepArgs> want((size_t)n);
     for (int i = 0; i < n; ++i) {
@@ -1295,6 +1320,7 @@ int pcp_batch_icp_launch(pcp_batch* b, int mode, int max_iter, float tol, int fu
     if (max_iter < 0 || max_iter > pcp_ctx::max_iter_cap)
         return pcp_fail("max_iter = %d outside [0, %d]", max_iter, pcp_ctx::max_iter_cap);
     const int n = (int)b->ctxs.size();
+    if (n == 0) return pcp_fail("the batch holds no context any more");
     int max_nb = 0, max_scans = 0;
     std::vector<LsArgs> want_ls((size_t)n);
     std::vector<FinishArgs> want_fin((size_t)n);

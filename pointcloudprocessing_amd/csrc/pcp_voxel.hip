@@ -602,7 +602,8 @@ int pcp_voxel_insert_unknown(pcp_ctx* c, int max_points, int* new_stored, int* r
     PCP_CHECK(hipStreamSynchronize(s));
     int bits = 1;
     for (int a = 0; a < 3; ++a) {
-        if (mm[a] < -(1 << 20) || mm[3 + a] > (1 << 20)) return pcp_fail("voxel coordinate beyond +-2^20");
+        // 21 bits per axis at most: three of them fill the 63 key bits (|c| < 2^20, the host statement's own limit)
+        if (mm[a] <= -(1 << 20) || mm[3 + a] >= (1 << 20)) return pcp_fail("voxel coordinate beyond +-2^20");
         while ((1ll << bits) < (long long)mm[3 + a] - mm[a] + 1) ++bits;
     }
     // (key, id) in point order, stable sort by key, group heads

@@ -122,6 +122,10 @@ def test_distance_upper_bound_and_far_queries(frames):
         ref_d, ref_i = NG.exact_nn(a, q)
         dist, idx = g.query(q)
         assert_same_neighbours(a, q, idx, dist, ref_i, ref_d)
+        # nothing is strictly nearer than a bound of 0 (or below): all misses, as scipy's KDTree.query answers
+        for bound in (0.0, -1.0, float("nan")):
+            dist, idx = g.query(q, distance_upper_bound=bound)
+            assert np.all(np.isinf(dist)) and np.all(idx == len(a))
     finally:
         g.cleanup()
 

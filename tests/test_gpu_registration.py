@@ -289,6 +289,32 @@ def test_batched_pairs_equal_single_pair_runs():
             cs.cleanup()
 
 
+def test_a_context_may_be_destroyed_before_its_batch():
+    """pcp_destroy of an adopted context takes it out of the batch; the batch keeps working with the rest."""
+    from pointcloudprocessing_amd import ComputeShader, IcpBatch
+    a, b = small_pair()
+    computes = []
+    for _ in range(3):
+        cs = ComputeShader(maxPointsPerCloud=max(len(a), len(b)), maxScans=100)
+        PointcloudIcpContainer(cs).preparePointToPlane(a, ORIGIN, b)
+        computes.append(cs)
+    want = computes[0].icpRun(b, MODE_PLANE, 4)
+    batch = IcpBatch(computes)
+    lib = computes[1]._lib
+    assert lib.pcp_set_stream(computes[1]._ctx, None) != 0 and b"batch" in lib.pcp_last_error()
+    batch.upload_sources([b, b, b])
+    computes[1].cleanup()                   # in the middle of the batch's life
+    batch.computes = [computes[0], computes[2]]
+    batch.prepare(True)
+    batch.launch(MODE_PLANE, 4)
+    for dx, conv, _, _ in batch.results(4):
+        assert np.array_equal(bits(dx), bits(want[0])) and conv == want[1]
+    batch.close()
+    computes[0].synchronize()               # on its own stream again
+    for cs in (computes[0], computes[2]):
+        cs.cleanup()
+
+
 # ------------------------------------------------------------------------------ errors
 def test_error_paths(compute):
     from pointcloudprocessing_amd import PcpError

@@ -299,6 +299,18 @@ def test_voxel_insertion_error_paths(compute):
     assert lib.pcp_voxel_insert_unknown(ctx, 1024, C.byref(stored), C.byref(cap)) != 0      # already consumed
     with pytest.raises(RuntimeError):
         v.addPoints(np.array([[3e6, 0.0, 0.0]]), None)                                        # beyond +-2^20 voxels
+    # the boundary itself: |coordinate| = 2^20 - 1 is the last one three 21-bit fields can key apart
+    edge = float(2 ** 20 - 1)
+    v2 = Voxelizer(compute, None)
+    v2.init(1.0)
+    v2.addPoints(np.array([[edge, 0.5, 0.5], [-edge + 0.5, 0.5, 0.5], [edge, 1.5, 0.5]]), None)
+    assert v2.stored_voxels == 3
+    assert sorted(v2.voxel_index[:3, 0].tolist()) == [-(2 ** 20 - 1) + 1, 2 ** 20 - 1, 2 ** 20 - 1]
+    for bad in (float(2 ** 20), -float(2 ** 20) - 0.5):
+        v3 = Voxelizer(compute, None)
+        v3.init(1.0)
+        with pytest.raises(RuntimeError, match="beyond"):
+            v3.addPoints(np.array([[bad, 0.5, 0.5], [0.5, 0.5, 0.5]]), None)
 
 
 def test_transposed_clouds_are_fed_as_coordinate_rows(compute):
