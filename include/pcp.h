@@ -351,6 +351,30 @@ int pcp_grid_pose_dev(pcp_grid* grid, const float* tile_dev, int mode, int max_i
 int pcp_grid_icp_finish(pcp_grid* grid);
 int pcp_grid_icp_fetch(pcp_grid* grid, float* dx_trace, float* hb_trace, int* iters, int* converged, int* done);
 
+/* ---- the exchange step of a map split over GPUs, behind the ABI ---------------------------------
+ * One rank per GPU (one process per GPU, or one thread per GPU of a process).  The communicator is
+ * RCCL's (bound at run time: $PCP_RCCL_PATH, a copy already loaded into the process, or the loader
+ * path); the only collective the path needs is the sum all-reduce of the 8x8 float32 tile between
+ * pcp_grid_ls_dev and pcp_grid_pose_dev.  No counterpart in the reference (single GPU, no collective). */
+typedef struct pcp_comm pcp_comm;
+#define PCP_COMM_ID_BYTES 128
+/* Rank 0 makes the id (ncclGetUniqueId) and hands its 128 bytes to the other ranks by any means. */
+int pcp_comm_unique_id(char* id128);
+/* Collective: every rank of the world calls it with the same id (ncclCommInitRank). */
+int pcp_comm_init(int device, int world, int rank, const char* id128, pcp_comm** out);
+int pcp_comm_destroy(pcp_comm* comm);
+int pcp_comm_info(pcp_comm* comm, int* world, int* rank);
+/* In-place sum of 64 floats in device memory over all ranks, enqueued on hip_stream. */
+int pcp_comm_allreduce_tile(pcp_comm* comm, float* tile_dev, void* hip_stream);
+/* The same on the grid's stream, i.e. ordered between pcp_grid_ls_dev and pcp_grid_pose_dev. */
+int pcp_grid_allreduce_tile(pcp_grid* grid, pcp_comm* comm, float* tile_dev);
+/* pcp_grid_icp_run for a map split over the ranks of comm: every rank holds its share of the map
+ * (pcp_grid_build_slab), its key range (pcp_grid_set_owned_keys) and the whole scan as working copy
+ * (pcp_grid_source); per iteration partial tile -> all-reduce -> solve, every rank solving the same
+ * system; all ranks return the same steps.  With a world of 1 the result equals pcp_grid_icp_run. */
+int pcp_grid_icp_run_comm(pcp_grid* grid, pcp_comm* comm, int mode, double radius, int max_iter, float tol,
+                          int full_iter, float* dx_trace, float* hb_trace, int* iters, int* converged);
+
 /* ---------------------------------------------------------------------------
  * Frame preparation on the device: KITTI decode + ego filter + axis rotation
  * (LidarDataReader.eatBytes :144-150, :59-61, :66-67), the IMU pre-alignment

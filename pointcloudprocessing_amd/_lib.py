@@ -88,6 +88,14 @@ SIGNATURES = {
     "pcp_grid_pose_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_int]),
     "pcp_grid_icp_finish": (C.c_int, [C.c_void_p]),
     "pcp_grid_icp_fetch": (C.c_int, [C.c_void_p, _f32p, _f32p, _i32p, _i32p, _i32p]),
+    "pcp_comm_unique_id": (C.c_int, [C.c_char_p]),
+    "pcp_comm_init": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_char_p, C.POINTER(C.c_void_p)]),
+    "pcp_comm_destroy": (C.c_int, [C.c_void_p]),
+    "pcp_comm_info": (C.c_int, [C.c_void_p, _i32p, _i32p]),
+    "pcp_comm_allreduce_tile": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pcp_grid_allreduce_tile": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pcp_grid_icp_run_comm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_float, C.c_int, _f32p, _f32p,
+                                        _i32p, _i32p]),
     "pcp_set_target_dev": (C.c_int, [_ctx, C.c_void_p, C.c_int, _u32p, C.c_int, _f32p]),
     "pcp_frame_create": (C.c_int, [C.c_int, C.c_size_t, C.POINTER(C.c_void_p)]),
     "pcp_frame_destroy": (C.c_int, [C.c_void_p]),
@@ -140,9 +148,15 @@ def _share_torch_hip_runtime():
         spec = None
     if spec is None or not spec.submodule_search_locations:
         return
-    path = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    libdir = os.path.join(list(spec.submodule_search_locations)[0], "lib")
+    path = os.path.join(libdir, "libamdhip64.so")
     if os.path.exists(path):
         C.CDLL(path, mode=C.RTLD_GLOBAL)
+    # the same for RCCL: pcp_comm_* binds it at run time and is pointed at PyTorch's copy, so that a process
+    # using both torch.distributed and the library's own communicator holds one RCCL
+    rccl = os.path.join(libdir, "librccl.so")
+    if os.path.exists(rccl):
+        os.environ.setdefault("PCP_RCCL_PATH", rccl)
 
 
 def load():

@@ -995,6 +995,7 @@ inline unsigned blocks_for(size_t n, int threads) { return (unsigned)((n + threa
 struct pcp_grid {
     int device = 0;
     hipStream_t own_stream = nullptr, stream = nullptr;
+    float* comm_tile = nullptr;      // 64 floats: the partial tile of pcp_grid_icp_run_comm, made on first use
     // map
     size_t n = 0, cap = 0;
     double cell = 0.0;
@@ -1208,7 +1209,7 @@ int pcp_grid_destroy(pcp_grid* g) {
     PCP_CHECK(hipStreamSynchronize(g->stream));
     if (free_map(g) || free_source(g)) return 1;
     void* p[] = {g->state, g->hb_trace, g->dx_trace, g->tile, g->sel_state, g->sel_hist, g->kd_partial, g->kd_out,
-                 g->rt, g->mm, g->cell_count};
+                 g->rt, g->mm, g->cell_count, g->comm_tile};
     for (void* q : p) if (q) PCP_CHECK(hipFree(q));
     for (hipEvent_t e : {g->ev0, g->ev1, g->ev2, g->ev3}) if (e) PCP_CHECK(hipEventDestroy(e));
     PCP_CHECK(hipStreamDestroy(g->own_stream));
@@ -1741,6 +1742,31 @@ int pcp_grid_icp_run(pcp_grid* g, int mode, double radius, int max_iter, float t
                            max_iter, tol, full_iter);
     }
     PCP_CHECK(hipGetLastError());
+    if (pcp_grid_icp_finish(g)) return 1;
+    return pcp_grid_icp_fetch(g, dx_trace, hb_trace, iters, converged, nullptr);
+}
+
+int pcp_grid_allreduce_tile(pcp_grid* g, pcp_comm* comm, float* tile_dev) {
+    if (!g) return pcp_fail("null grid");
+    return pcp_comm_allreduce_tile(comm, tile_dev, (void*)g->stream);
+}
+
+int pcp_grid_icp_run_comm(pcp_grid* g, pcp_comm* comm, int mode, double radius, int max_iter, float tol, int full_iter,
+                          float* dx_trace, float* hb_trace, int* iters, int* converged) {
+    if (check_source(g)) return 1;
+    if (!comm) return pcp_fail("null communicator");
+    if (max_iter < 1 || max_iter > pcp_grid::max_iter_cap) return pcp_fail("max_iter must be in [1, %d]", pcp_grid::max_iter_cap);
+    PCP_CHECK(hipSetDevice(g->device));
+    if (!g->comm_tile) PCP_CHECK(hipMalloc(&g->comm_tile, 64 * sizeof(float)));
+    if (pcp_grid_icp_reset(g)) return 1;
+    // Every rank enqueues the same max_iter exchanges: the summed tile, hence the solved step and the
+    // convergence flag, are identical on all ranks, and once a rank's loop is done its launches return at
+    // once while the (256-byte) all-reduces keep the ranks in step.
+    for (int it = 0; it < max_iter; ++it) {
+        if (pcp_grid_ls_dev(g, mode, radius, g->comm_tile)) return 1;
+        if (pcp_comm_allreduce_tile(comm, g->comm_tile, (void*)g->stream)) return 1;
+        if (pcp_grid_pose_dev(g, g->comm_tile, mode, max_iter, tol, full_iter)) return 1;
+    }
     if (pcp_grid_icp_finish(g)) return 1;
     return pcp_grid_icp_fetch(g, dx_trace, hb_trace, iters, converged, nullptr);
 }

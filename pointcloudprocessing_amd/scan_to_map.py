@@ -72,6 +72,45 @@ def slab_mask(map_points, cell, lo, hi):
     return mask
 
 
+class RcclComm:
+    """The library's own RCCL communicator (pcp_comm_*): one rank per GPU.  The 128-byte id made by rank 0
+    reaches the other ranks through `share`, a callable taking rank 0's bytes (None elsewhere) and returning
+    them on every rank; by default a torch.distributed broadcast (any backend) when world > 1."""
+
+    def __init__(self, rank=0, world=1, device=0, share=None):
+        import ctypes as C
+        from . import _lib
+        self._lib = _lib.load()
+        self.rank, self.world, self.device = int(rank), int(world), int(device)
+        ident = None
+        if self.rank == 0:
+            buf = C.create_string_buffer(128)
+            _lib.check(self._lib.pcp_comm_unique_id(buf))
+            ident = buf.raw
+        if self.world > 1:
+            if share is None:
+                import torch.distributed as dist
+
+                def share(b):
+                    box = [b]
+                    dist.broadcast_object_list(box, src=0)
+                    return box[0]
+            ident = share(ident)
+        self._comm = C.c_void_p()
+        _lib.check(self._lib.pcp_comm_init(self.device, self.world, self.rank, ident, C.byref(self._comm)))
+
+    def close(self):
+        if self._comm:
+            self._lib.pcp_comm_destroy(self._comm)
+            self._comm = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class HipMapBackend:
     """The product backend: a CellGrid on this rank's device."""
 
@@ -137,6 +176,23 @@ class HipMapBackend:
     def finish(self):
         self._check(self._lib.pcp_grid_icp_finish(self.grid._g))
 
+    def all_reduce_rccl(self, comm, tile):
+        """The exchange step through the library's communicator, on the grid's stream."""
+        self._check(self._lib.pcp_grid_allreduce_tile(self.grid._g, comm._comm, tile.data_ptr()))
+        return tile
+
+    def run_comm(self, comm, mode, radius, max_iter, tol, full_iter):
+        """The whole partitioned loop in one ABI call (pcp_grid_icp_run_comm)."""
+        import ctypes as C
+        from ._lib import f32p
+        dx = np.zeros((max_iter, 6), dtype=np.float32)
+        hb = np.zeros((max_iter, 8, 8), dtype=np.float32)
+        it, cv = C.c_int(0), C.c_int(0)
+        self._check(self._lib.pcp_grid_icp_run_comm(self.grid._g, comm._comm, int(mode), float(radius), int(max_iter),
+                                                    float(tol), 1 if full_iter else 0, f32p(dx), f32p(hb),
+                                                    C.byref(it), C.byref(cv)))
+        return dx[:it.value], bool(cv.value), hb[:it.value]
+
     def fetch(self, max_iter):
         import ctypes as C
         from ._lib import f32p
@@ -163,12 +219,17 @@ class MapRegistration:
     CPU checker); group: a torch.distributed process group, None = the default one when world > 1."""
 
     def __init__(self, map_points, cell, normals=None, rank=0, world=1, device=0, backend=None, group=None,
-                 nn_cell=None):
+                 nn_cell=None, comm=None):
         """cell: edge of the partition cells (ownership and halo; the search radius may not exceed it).
         nn_cell: edge of the search grid's cells on each rank (default: cell); dense maps want it
-        smaller, a few point spacings."""
+        smaller, a few point spacings.
+        comm: an RcclComm -- the exchange step then runs inside the library (pcp_grid_icp_run_comm /
+        pcp_grid_allreduce_tile) instead of through torch.distributed."""
         self.rank, self.world, self.cell = int(rank), int(world), float(cell)
         self.group = group
+        self.comm = comm
+        if comm is not None and (comm.world != self.world or comm.rank != self.rank):
+            raise ValueError("the communicator's rank / world differ from the registration's")
         self.backend = backend if backend is not None else HipMapBackend(device)
         pts = np.asarray(map_points, dtype=np.float64)[:, :3]
         on_device = hasattr(self.backend, "partition")
@@ -191,6 +252,8 @@ class MapRegistration:
         self.backend.set_owned(lo, hi)
 
     def _all_reduce(self, tile):
+        if self.comm is not None:
+            return self.backend.all_reduce_rccl(self.comm, tile)
         if self.world == 1:
             return tile
         import contextlib
@@ -214,6 +277,13 @@ class MapRegistration:
             raise ValueError("the search radius must not exceed the cell size (one-cell halo)")
         b = self.backend
         b.set_source(scan)
+        if self.comm is not None and check_every is None:
+            # one ABI call: all max_iter exchanges enqueued by the library itself
+            dx, converged, hb = b.run_comm(self.comm, mode, radius, max_iter, tol, full_iter)
+            applied = len(dx) - 1 if (converged and mode == MODE_PLANE and not full_iter) else len(dx)
+            t_opt, R_opt = PointcloudIcpContainer(None)._replay(dx, applied)
+            self.last_tiles = hb
+            return t_opt, R_opt, dx, converged
         b.reset()
         for it in range(max_iter):
             tile = self._all_reduce(b.partial_tile(mode, radius))

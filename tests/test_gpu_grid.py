@@ -302,6 +302,30 @@ def test_map_registration_driver_equals_the_fused_loop_bitwise(mode):
         reg.close()
 
 
+@pytest.mark.parametrize("mode", [0, 1])
+def test_exchange_step_inside_the_library_single_rank_communicator(mode):
+    """pcp_comm_* / pcp_grid_icp_run_comm with a world of one: the RCCL all-reduce of one tile is the identity,
+    so both the one-call loop and the per-iteration driver must reproduce pcp_grid_icp_run bit for bit.  (A world
+    of two needs two GPUs: RCCL refuses two ranks on one device.)"""
+    from pointcloudprocessing_amd import scan_to_map as S
+    world, nrm, src = _map_scene()
+    g = CellGrid(world, cell=0.5, normals=nrm)
+    comm = S.RcclComm(rank=0, world=1, device=0)
+    reg = S.MapRegistration(world, 0.5, normals=nrm, comm=comm)
+    try:
+        g.set_source(src)
+        dx_ref, conv_ref, hb_ref = g.icp_run(mode, 0.4, max_iter=8)
+        for check_every in (None, 1):                       # one ABI call / stepwise with the all-reduce per iteration
+            t_opt, R_opt, dx, conv = reg.register(src, mode, 0.4, max_iter=8, check_every=check_every)
+            assert conv == conv_ref and np.array_equal(bits(dx), bits(dx_ref)), check_every
+            assert np.array_equal(bits(reg.last_tiles), bits(hb_ref))
+            assert np.array_equal(reg.moved_scan(), g.read_source())
+    finally:
+        g.cleanup()
+        reg.close()
+        comm.close()
+
+
 MAP_WORKER = r'''
 import os, sys
 import numpy as np
