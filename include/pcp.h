@@ -278,6 +278,20 @@ int pcp_grid_build(pcp_grid* grid, const double* xyz, size_t n, double cell, con
 int pcp_grid_partition(int device, const double* xyz, size_t n, double own_cell, int world, unsigned long long* cuts);
 int pcp_grid_build_slab(pcp_grid* grid, const double* xyz, size_t n, double cell, const float* normals_xyzw,
                         double own_cell, unsigned long long lo, unsigned long long hi, size_t* n_kept);
+/* New points join the resident map without a rebuild: the batch is sorted by cell key on its own, merged
+ * into the map's order (a cell's points stay in the order of their ids) and the cell table is redone from
+ * the merged keys.  This is how a map accumulates: the reference's Voxelizer hands the points of the voxels
+ * it stages to its VoxelManager frame by frame (Voxelizer.py:130-133, VoxelManager.frameVoxelized :31-45);
+ * here they go into the grid scans are registered against.  Ids are first_id + row index, so that feeding
+ * batches with first_id = points fed before gives the map pcp_grid_build makes of all of them at once:
+ * same order, same cells, same answers.  Needs a prior pcp_grid_build (which fixes the cell size; n = 0 is
+ * fine).  A map with caller-supplied normals needs normals for every batch; normals estimated by
+ * pcp_grid_estimate_normals are dropped by an append (estimate again).  The _slab form keeps only the
+ * points in or next to the caller's share of the partition-cell key space, as pcp_grid_build_slab does:
+ * every rank is handed the same batch and keeps its own part (n_kept). */
+int pcp_grid_append(pcp_grid* grid, const double* xyz, size_t n, const float* normals_xyzw, long long first_id);
+int pcp_grid_append_slab(pcp_grid* grid, const double* xyz, size_t n, const float* normals_xyzw, double own_cell,
+                         unsigned long long lo, unsigned long long hi, long long first_id, size_t* n_kept);
 /* Facts about the last build: points, occupied cells, extent in cells, radix
  * passes, device time of the whole build and of the sort alone (ms). Any pointer may be NULL. */
 int pcp_grid_info(pcp_grid* grid, unsigned long long* n_points, unsigned long long* n_cells, int* extent3,

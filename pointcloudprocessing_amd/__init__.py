@@ -14,3 +14,4 @@ from .frame import DeviceFrame  # noqa: F401
 from .oxts import OXTS, OxtsDataReader  # noqa: F401
 from .voxelizer import Voxelizer  # noqa: F401
 from .sequence import PinnedFrames, SequencePipeline  # noqa: F401
+from .map_sink import MapSink  # noqa: F401

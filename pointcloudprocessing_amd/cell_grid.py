@@ -61,6 +61,32 @@ class CellGrid:
             self.held = int(kept.value)
         self.m = 0
 
+    def append(self, np_points, normals=None, first_id=None, slab=None):
+        """New points join the resident map without a rebuild (pcp_grid_append): sorted among themselves,
+        merged into the map's order, cell table redone.  Ids continue where the points fed so far end
+        (first_id overrides), so query results index the concatenation of everything fed.  With
+        slab = (own_cell, lo, hi) only this rank's share of the batch is kept (pcp_grid_append_slab).
+        Returns the number of points kept."""
+        pts = np.ascontiguousarray(np.asarray(np_points, dtype=np.float64)[:, :3])
+        first = self.n if first_id is None else int(first_id)
+        nrm = None
+        if normals is not None:
+            nrm = np.zeros((len(pts), 4), dtype=np.float32)
+            nn = np.asarray(normals, dtype=np.float32)
+            nrm[:, :nn.shape[1]] = nn
+        if slab is None:
+            check(self._lib.pcp_grid_append(self._g, f64p(pts), len(pts), f32p(nrm), first))
+            kept = len(pts)
+        else:
+            k = C.c_size_t(0)
+            check(self._lib.pcp_grid_append_slab(self._g, f64p(pts), len(pts), f32p(nrm), float(slab[0]), int(slab[1]),
+                                                 int(slab[2]), first, C.byref(k)))
+            kept = int(k.value)
+        self.n = max(self.n, first + len(pts))              # ids handed out so far: what a miss is reported as
+        self.held += kept
+        self.data = None                                    # the host copy of the first build no longer is the map
+        return kept
+
     def info(self):
         n, cells = C.c_ulonglong(0), C.c_ulonglong(0)
         ext = np.zeros(3, dtype=np.int32)

@@ -72,6 +72,17 @@ __host__ __device__ inline unsigned long long morton3(unsigned x, unsigned y, un
     return spread21(x) | (spread21(y) << 1) | (spread21(z) << 2);
 }
 
+// Key of a cell from its ABSOLUTE coordinates: zig-zag per axis (0, -1, 1, -2, ... -> 0, 1, 2, 3, ...), then
+// bit interleaving.  A function of the cell alone, not of the map's bounding box, so points appended
+// later sort into the very order a build of the whole would give them; and the cells of a map around the
+// origin still have short keys (few radix passes).
+__host__ __device__ inline unsigned zigzag(const int c) {
+    return c >= 0 ? ((unsigned)c << 1) : ((((unsigned)(-(c + 1))) << 1) | 1u);
+}
+__host__ __device__ inline unsigned long long cell_key(const int ax, const int ay, const int az) {
+    return morton3(zigzag(ax), zigzag(ay), zigzag(az));
+}
+
 __device__ __forceinline__ int cell_of(const double v, const double cell) {
     double f = floor(v / cell);
     f = fmin(fmax(f, -(double)COORD_CLAMP), (double)COORD_CLAMP);
@@ -146,14 +157,11 @@ k_cell_range(const double* __restrict__ xyz, size_t n, double cell, int* __restr
     }
 }
 
-__global__ void k_cell_keys(const double* __restrict__ xyz, size_t n, double cell, int cx, int cy, int cz,
+__global__ void k_cell_keys(const double* __restrict__ xyz, size_t n, double cell,
                             unsigned long long* __restrict__ keys, unsigned* __restrict__ vals) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const unsigned x = (unsigned)(cell_of(xyz[3 * i + 0], cell) - cx);
-    const unsigned y = (unsigned)(cell_of(xyz[3 * i + 1], cell) - cy);
-    const unsigned z = (unsigned)(cell_of(xyz[3 * i + 2], cell) - cz);
-    keys[i] = morton3(x, y, z);
+    keys[i] = cell_key(cell_of(xyz[3 * i + 0], cell), cell_of(xyz[3 * i + 1], cell), cell_of(xyz[3 * i + 2], cell));
     vals[i] = (unsigned)i;
 }
 
@@ -210,16 +218,55 @@ __device__ __forceinline__ bool find_cell(const Cell* __restrict__ table, const 
 }
 
 __global__ void k_gather_points(const double* __restrict__ xyz, const unsigned* __restrict__ vals, size_t n,
-                                const float4* __restrict__ normals_in, const unsigned* __restrict__ orig,
+                                const float4* __restrict__ normals_in, const unsigned* __restrict__ orig, long long first_id,
                                 GridPoint* __restrict__ pts, float4* __restrict__ normals) {
     const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n) return;
     const unsigned i = vals[j];
     GridPoint p;
     p.x = xyz[3 * (size_t)i + 0]; p.y = xyz[3 * (size_t)i + 1]; p.z = xyz[3 * (size_t)i + 2];
-    p.id = orig ? (long long)orig[i] : (long long)i;     // index in the caller's array
+    p.id = first_id + (orig ? (long long)orig[i] : (long long)i);     // index in the caller's array (+ what came before it)
     pts[j] = p;
     if (normals_in) normals[j] = normals_in[i];
+}
+
+// Merge of two runs sorted by key into one: every element finds its place by one binary search in the
+// OTHER run.  Equal keys keep the old run's elements in front, so ingesting batches one after the other
+// leaves a cell's points in the order of their ids, as one stable sort of everything would.
+__global__ void __launch_bounds__(256)
+k_merge_old(const unsigned long long* __restrict__ ko, size_t n, const unsigned long long* __restrict__ kn, size_t m,
+            const GridPoint* __restrict__ po, const float4* __restrict__ no, GridPoint* __restrict__ pout,
+            unsigned long long* __restrict__ kout, float4* __restrict__ nout) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const unsigned long long key = ko[i];
+    size_t lo = 0, hi = m;                       // first new element whose key is not below this one's
+    while (lo < hi) {
+        const size_t mid = lo + (hi - lo) / 2;
+        if (kn[mid] < key) lo = mid + 1; else hi = mid;
+    }
+    const size_t pos = i + lo;
+    pout[pos] = po[i];
+    kout[pos] = key;
+    if (no) nout[pos] = no[i];
+}
+
+__global__ void __launch_bounds__(256)
+k_merge_new(const unsigned long long* __restrict__ ko, size_t n, const unsigned long long* __restrict__ kn, size_t m,
+            const GridPoint* __restrict__ pn, const float4* __restrict__ nn, GridPoint* __restrict__ pout,
+            unsigned long long* __restrict__ kout, float4* __restrict__ nout) {
+    const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= m) return;
+    const unsigned long long key = kn[j];
+    size_t lo = 0, hi = n;                       // first old element whose key is above this one's
+    while (lo < hi) {
+        const size_t mid = lo + (hi - lo) / 2;
+        if (ko[mid] <= key) lo = mid + 1; else hi = mid;
+    }
+    const size_t pos = j + lo;
+    pout[pos] = pn[j];
+    kout[pos] = key;
+    if (nn) nout[pos] = nn[j];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -260,7 +307,7 @@ __device__ __forceinline__ void visit_cell(const GridView& G, const int x, const
     const double boxd2 = (gx * gx + gy * gy) + gz * gz;
     if (boxd2 > best) return;
     unsigned start, count;
-    if (!find_cell(G.table, G.log_cap, morton3((unsigned)x, (unsigned)y, (unsigned)z), start, count)) return;
+    if (!find_cell(G.table, G.log_cap, cell_key(x + G.cminx, y + G.cminy, z + G.cminz), start, count)) return;
     if (count > CROWDED && D.n < DEFER_SLOTS) {
 #pragma unroll
         for (int e = 0; e < DEFER_SLOTS; ++e)
@@ -434,7 +481,7 @@ __global__ void __launch_bounds__(256) k_grid_nn32(const Nn32Args A) {
             // a shell of one cell (the query's own): its points, not the cells, are dealt out to the lanes,
             // so the shells after it start from a tight best distance
             unsigned start, count;
-            if (find_cell(G.table, G.log_cap, morton3((unsigned)x0, (unsigned)y0, (unsigned)z0), start, count))
+            if (find_cell(G.table, G.log_cap, cell_key(x0 + G.cminx, y0 + G.cminy, z0 + G.cminz), start, count))
                 for (unsigned j = start + sub; j < start + count; j += 32) take_point(G.pts[j], j, qx, qy, qz, best, bid, bpos);
         } else {
             // 32 cells at a time: every lane looks ONE cell up, then the points of the cells found are
@@ -458,7 +505,7 @@ __global__ void __launch_bounds__(256) k_grid_nn32(const Nn32Args A) {
                         const double gy = axis_gap(qy, (double)(y + G.cminy) * G.cell, (double)(y + G.cminy + 1) * G.cell, G.eps);
                         const double gz = axis_gap(qz, (double)(z + G.cminz) * G.cell, (double)(z + G.cminz + 1) * G.cell, G.eps);
                         if (!((gx * gx + gy * gy) + gz * gz > best))
-                            if (!find_cell(G.table, G.log_cap, morton3((unsigned)x, (unsigned)y, (unsigned)z), start, count)) count = 0;
+                            if (!find_cell(G.table, G.log_cap, cell_key(x + G.cminx, y + G.cminy, z + G.cminz), start, count)) count = 0;
                     }
                 }
                 unsigned inc = count;
@@ -725,7 +772,7 @@ __global__ void __launch_bounds__(256) k_grid_pca(const PcaArgs A) {
                 const double gy = axis_gap(q.y, (double)(y + G.cminy) * G.cell, (double)(y + G.cminy + 1) * G.cell, G.eps);
                 const double gz = axis_gap(q.z, (double)(z + G.cminz) * G.cell, (double)(z + G.cminz + 1) * G.cell, G.eps);
                 if ((gx * gx + gy * gy) + gz * gz < A.radius2)
-                    if (!find_cell(G.table, G.log_cap, morton3((unsigned)x, (unsigned)y, (unsigned)z), start, count)) count = 0;
+                    if (!find_cell(G.table, G.log_cap, cell_key(x + G.cminx, y + G.cminy, z + G.cminz), start, count)) count = 0;
             }
         }
         const int in_round = min(32, ncell - base);
@@ -1002,7 +1049,14 @@ struct pcp_grid {
     int cmin[3] = {0, 0, 0}, ext[3] = {0, 0, 0};
     GridPoint* pts = nullptr;
     float4* normals = nullptr;
+    unsigned long long* keys = nullptr;     // cell key of every entry of pts (sorted): what an append merges by
+    GridPoint* pts_alt = nullptr;           // second set of buffers an append merges into (then the sets swap)
+    float4* normals_alt = nullptr;
+    unsigned long long* keys_alt = nullptr;
+    size_t cap_alt = 0;
+    int lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};   // bounding cells of the map (cmin = lo, ext = hi - lo + 1)
     bool have_normals = false;
+    bool normals_estimated = false;         // the normals came from pcp_grid_estimate_normals, not from the caller
     Cell* table = nullptr;
     int log_cap = 0;
     size_t table_cap = 0;
@@ -1043,11 +1097,10 @@ GridView view_of(const pcp_grid* g) {
 }
 
 int free_map(pcp_grid* g) {
-    if (g->pts) PCP_CHECK(hipFree(g->pts));
-    if (g->normals) PCP_CHECK(hipFree(g->normals));
-    if (g->table) PCP_CHECK(hipFree(g->table));
-    g->pts = nullptr; g->normals = nullptr; g->table = nullptr;
-    g->cap = 0; g->table_cap = 0; g->n = 0;
+    void* p[] = {g->pts, g->normals, g->keys, g->pts_alt, g->normals_alt, g->keys_alt, g->table};
+    for (void* q : p) if (q) PCP_CHECK(hipFree(q));
+    g->pts = g->pts_alt = nullptr; g->normals = g->normals_alt = nullptr; g->keys = g->keys_alt = nullptr; g->table = nullptr;
+    g->cap = g->cap_alt = 0; g->table_cap = 0; g->n = 0; g->log_cap = 0;
     return 0;
 }
 
@@ -1231,19 +1284,48 @@ int pcp_grid_synchronize(pcp_grid* g) {
 }
 
 // Builds the grid from points already on the device (d_ids: original index of every point, or null).
-static int build_device(pcp_grid* g, const double* d_xyz, const float4* d_nrm, const unsigned* d_ids, size_t n, double cell) {
+// Bits of a cell key that can differ between two cells of the box [lo, hi]: per axis the zig-zag values of
+// the box's cells lie between two numbers, so they share those numbers' common binary prefix.
+static unsigned long long varying_key_bits(const int lo[3], const int hi[3]) {
+    unsigned long long mask = 0;
+    for (int a = 0; a < 3; ++a) {
+        unsigned zlo, zhi;
+        if (lo[a] < 0 && hi[a] >= 0) { zlo = 0; zhi = std::max(zigzag(lo[a]), zigzag(hi[a])); }
+        else if (hi[a] < 0) { zlo = zigzag(hi[a]); zhi = zigzag(lo[a]); }
+        else { zlo = zigzag(lo[a]); zhi = zigzag(hi[a]); }
+        int top = 0;
+        while (top < 32 && ((zlo ^ zhi) >> top) != 0) ++top;
+        const unsigned long long m = (top >= 21) ? 0x1FFFFFull : ((1ull << top) - 1ull);
+        mask |= spread21(m) << a;
+    }
+    return mask;
+}
+
+// A batch of points brought into key order on the device: what a build installs as the map and an
+// append merges into it.
+struct SortedRun {
+    GridPoint* pts = nullptr;
+    unsigned long long* keys = nullptr;
+    float4* normals = nullptr;
+    size_t n = 0;
+    int lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+    int passes = 0;
+    void release() {
+        for (void* q : {(void*)pts, (void*)keys, (void*)normals}) if (q) (void)hipFree(q);
+        pts = nullptr; keys = nullptr; normals = nullptr; n = 0;
+    }
+};
+
+// Keys, stable radix sort by key, points gathered into that order.  d_ids (or null) maps the rows of
+// d_xyz to indices in the caller's array; ids are first_id + that index.  Events ev0..ev2 bracket the
+// whole and the sort when `timed`.
+static int sort_run(pcp_grid* g, const double* d_xyz, const float4* d_nrm, const unsigned* d_ids, long long first_id,
+                    size_t n, double cell, bool timed, SortedRun* out) {
     hipStream_t s = g->stream;
-    if (free_map(g)) return 1;
-    g->cell = cell;
-    g->have_normals = false;
-    g->n_cells = 0;
-    g->sort_passes = 0;
-    g->ext[0] = g->ext[1] = g->ext[2] = 0;
-    g->nn_valid = false;
-    if (n == 0) return 0;
     unsigned long long *k0 = nullptr, *k1 = nullptr;
     unsigned *v0 = nullptr, *v1 = nullptr, *hist = nullptr, *totals = nullptr, *base = nullptr;
     const int nblk = (int)((n + RS_TILE - 1) / RS_TILE);
+    SortedRun run;
     auto cleanup = [&]() {
         for (void* q : {(void*)k0, (void*)k1, (void*)v0, (void*)v1, (void*)hist, (void*)totals, (void*)base})
             if (q) (void)hipFree(q);
@@ -1253,11 +1335,12 @@ static int build_device(pcp_grid* g, const double* d_xyz, const float4* d_nrm, c
         hipError_t e_ = (expr);                                                                             \
         if (e_ != hipSuccess) {                                                                             \
             cleanup();                                                                                      \
+            run.release();                                                                                  \
             return pcp_fail("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__);     \
         }                                                                                                   \
     } while (0)
-    GRID_TRY(hipEventRecord(g->ev0, s));
-    // cell range
+    if (timed) GRID_TRY(hipEventRecord(g->ev0, s));
+    // bounding cells
     const int init[8] = {INT_MAX, INT_MAX, INT_MAX, INT_MIN, INT_MIN, INT_MIN, 0, 0};
     GRID_TRY(hipMemcpyAsync(g->mm, init, sizeof(init), hipMemcpyHostToDevice, s));
     hipLaunchKernelGGL(k_cell_range, dim3(std::min<unsigned>(blocks_for(n, 256), 2048)), dim3(256), 0, s, d_xyz, n, cell, g->mm);
@@ -1268,14 +1351,7 @@ static int build_device(pcp_grid* g, const double* d_xyz, const float4* d_nrm, c
         cleanup();
         return pcp_fail("map coordinates must be finite and within 2^20 cells of the origin");
     }
-    int bits = 1;
-    for (int a = 0; a < 3; ++a) {
-        g->cmin[a] = mm[a];
-        g->ext[a] = mm[3 + a] - mm[a] + 1;
-        while ((1 << bits) < g->ext[a]) ++bits;
-    }
-    const int passes = (3 * bits + 7) / 8;
-    g->sort_passes = passes;
+    for (int a = 0; a < 3; ++a) { run.lo[a] = mm[a]; run.hi[a] = mm[3 + a]; }
     // keys + sort
     GRID_TRY(hipMalloc(&k0, n * 8));
     GRID_TRY(hipMalloc(&k1, n * 8));
@@ -1284,42 +1360,146 @@ static int build_device(pcp_grid* g, const double* d_xyz, const float4* d_nrm, c
     GRID_TRY(hipMalloc(&hist, (size_t)256 * nblk * 4));
     GRID_TRY(hipMalloc(&totals, 256 * 4));
     GRID_TRY(hipMalloc(&base, 256 * 4));
-    hipLaunchKernelGGL(k_cell_keys, dim3(blocks_for(n, 256)), dim3(256), 0, s, d_xyz, n, cell, g->cmin[0], g->cmin[1],
-                       g->cmin[2], k0, v0);
-    GRID_TRY(hipEventRecord(g->ev1, s));
+    hipLaunchKernelGGL(k_cell_keys, dim3(blocks_for(n, 256)), dim3(256), 0, s, d_xyz, n, cell, k0, v0);
+    if (timed) GRID_TRY(hipEventRecord(g->ev1, s));
     unsigned long long* kin = nullptr;
     unsigned* vin = nullptr;
-    radix_sort_pairs(s, k0, k1, v0, v1, n, 8 * passes, hist, totals, base, &kin, &vin);
-    GRID_TRY(hipEventRecord(g->ev2, s));
+    run.passes = radix_sort_pairs_varying(s, k0, k1, v0, v1, n, varying_key_bits(run.lo, run.hi), hist, totals, base, &kin, &vin);
+    if (timed) GRID_TRY(hipEventRecord(g->ev2, s));
     GRID_TRY(hipGetLastError());
-    // occupied cells -> hash table
-    GRID_TRY(hipMemsetAsync(g->cell_count, 0, 8, s));
-    hipLaunchKernelGGL(k_count_cells, dim3(std::min<unsigned>(blocks_for(n, 256), 2048)), dim3(256), 0, s, kin, n, g->cell_count);
-    unsigned long long cells = 0;
-    GRID_TRY(hipMemcpyAsync(&cells, g->cell_count, 8, hipMemcpyDeviceToHost, s));
+    GRID_TRY(hipMalloc(&run.pts, n * sizeof(GridPoint)));
+    if (d_nrm) GRID_TRY(hipMalloc(&run.normals, n * 16));
+    hipLaunchKernelGGL(k_gather_points, dim3(blocks_for(n, 256)), dim3(256), 0, s, d_xyz, vin, n, d_nrm, d_ids, first_id,
+                       run.pts, run.normals);
+    GRID_TRY(hipGetLastError());
+    // the sorted keys stay (in whichever of the two sort buffers they ended); everything else goes
+    run.keys = kin;
+    if (kin == k0) k0 = nullptr; else k1 = nullptr;
     GRID_TRY(hipStreamSynchronize(s));
+#undef GRID_TRY
+    cleanup();
+    run.n = n;
+    *out = run;
+    return 0;
+}
+
+// Occupied cells of the resident sorted keys -> hash table (key -> first entry, count), sized by the
+// rule capacity = smallest power of two >= 2 x cells; reallocated only when that size changes.
+static int install_table(pcp_grid* g) {
+    hipStream_t s = g->stream;
+    PCP_CHECK(hipMemsetAsync(g->cell_count, 0, 8, s));
+    hipLaunchKernelGGL(k_count_cells, dim3(std::min<unsigned>(blocks_for(g->n, 256), 2048)), dim3(256), 0, s, g->keys, g->n, g->cell_count);
+    unsigned long long cells = 0;
+    PCP_CHECK(hipMemcpyAsync(&cells, g->cell_count, 8, hipMemcpyDeviceToHost, s));
+    PCP_CHECK(hipStreamSynchronize(s));
     g->n_cells = cells;
     int log_cap = 4;
     while ((1ull << log_cap) < 2 * cells) ++log_cap;
-    g->log_cap = log_cap;
-    g->table_cap = (size_t)1 << log_cap;
-    GRID_TRY(hipMalloc(&g->table, g->table_cap * sizeof(Cell)));
-    GRID_TRY(hipMemsetAsync(g->table, 0xFF, g->table_cap * sizeof(Cell), s));
-    hipLaunchKernelGGL(k_insert_cells, dim3(blocks_for(n, 256)), dim3(256), 0, s, kin, n, g->table, log_cap);
-    GRID_TRY(hipMalloc(&g->pts, n * sizeof(GridPoint)));
-    if (d_nrm) GRID_TRY(hipMalloc(&g->normals, n * 16));
-    hipLaunchKernelGGL(k_gather_points, dim3(blocks_for(n, 256)), dim3(256), 0, s, d_xyz, vin, n, d_nrm, d_ids, g->pts, g->normals);
-    GRID_TRY(hipEventRecord(g->ev3, s));
-    GRID_TRY(hipGetLastError());
-    GRID_TRY(hipStreamSynchronize(s));
-    GRID_TRY(hipEventElapsedTime(&g->build_ms, g->ev0, g->ev3));
-    GRID_TRY(hipEventElapsedTime(&g->sort_ms, g->ev1, g->ev2));
-#undef GRID_TRY
-    cleanup();
+    if (!g->table || log_cap != g->log_cap) {
+        if (g->table) PCP_CHECK(hipFree(g->table));
+        g->table = nullptr;
+        g->log_cap = log_cap;
+        g->table_cap = (size_t)1 << log_cap;
+        PCP_CHECK(hipMalloc(&g->table, g->table_cap * sizeof(Cell)));
+    }
+    PCP_CHECK(hipMemsetAsync(g->table, 0xFF, g->table_cap * sizeof(Cell), s));
+    hipLaunchKernelGGL(k_insert_cells, dim3(blocks_for(g->n, 256)), dim3(256), 0, s, g->keys, g->n, g->table, g->log_cap);
+    PCP_CHECK(hipGetLastError());
+    return 0;
+}
+
+static void set_bounds(pcp_grid* g, const int lo[3], const int hi[3]) {
+    for (int a = 0; a < 3; ++a) {
+        g->lo[a] = lo[a]; g->hi[a] = hi[a];
+        g->cmin[a] = lo[a];
+        g->ext[a] = hi[a] - lo[a] + 1;
+    }
+}
+
+static int build_device(pcp_grid* g, const double* d_xyz, const float4* d_nrm, const unsigned* d_ids, size_t n, double cell) {
+    hipStream_t s = g->stream;
+    if (free_map(g)) return 1;
+    g->cell = cell;
+    g->have_normals = d_nrm != nullptr;
+    g->normals_estimated = false;
+    g->n_cells = 0;
+    g->sort_passes = 0;
+    g->ext[0] = g->ext[1] = g->ext[2] = 0;
+    g->nn_valid = false;
+    if (n == 0) return 0;
+    SortedRun run;
+    if (sort_run(g, d_xyz, d_nrm, d_ids, 0, n, cell, true, &run)) return 1;
+    // the run's buffers become the map
+    g->pts = run.pts; g->keys = run.keys; g->normals = run.normals;
     g->n = n;
     g->cap = n;
-    g->have_normals = d_nrm != nullptr;
+    g->sort_passes = run.passes;
+    set_bounds(g, run.lo, run.hi);
+    if (install_table(g)) return 1;
+    PCP_CHECK(hipEventRecord(g->ev3, s));
+    PCP_CHECK(hipStreamSynchronize(s));
+    PCP_CHECK(hipEventElapsedTime(&g->build_ms, g->ev0, g->ev3));
+    PCP_CHECK(hipEventElapsedTime(&g->sort_ms, g->ev1, g->ev2));
     return 0;
+}
+
+// Points already on the device join the resident map: sorted among themselves, merged into the second
+// set of buffers (which then becomes the first), table rebuilt from the merged keys.  The result is the
+// map a build of all points in order of their ids would give: same order, same cells.
+static int append_device(pcp_grid* g, const double* d_xyz, const float4* d_nrm, const unsigned* d_ids, long long first_id, size_t m) {
+    hipStream_t s = g->stream;
+    if (m == 0) return 0;
+    if (g->n + m >= (1ull << 31)) return pcp_fail("%zu map points exceed the 2^31 limit of one grid", g->n + m);
+    if (g->n && g->have_normals && !d_nrm) {
+        if (!g->normals_estimated) return pcp_fail("the map carries the caller's normals: appended points need them too");
+        g->have_normals = false;              // estimated from the map as it was: stale now, estimate again
+        g->normals_estimated = false;
+        for (float4** q : {&g->normals, &g->normals_alt}) { if (*q) (void)hipFree(*q); *q = nullptr; }
+    }
+    if (g->n && !g->have_normals && d_nrm) return pcp_fail("the map carries no normals");
+    g->nn_valid = false;
+    SortedRun run;
+    if (sort_run(g, d_xyz, d_nrm, d_ids, first_id, m, g->cell, false, &run)) return 1;
+    g->sort_passes = run.passes;
+    if (g->n == 0) {
+        if (free_map(g)) { run.release(); return 1; }
+        g->pts = run.pts; g->keys = run.keys; g->normals = run.normals;
+        g->n = g->cap = m;
+        g->have_normals = d_nrm != nullptr;
+        set_bounds(g, run.lo, run.hi);
+        return install_table(g);
+    }
+    const size_t total = g->n + m;
+    if (g->cap_alt < total || (g->have_normals && !g->normals_alt)) {      // grow by half at least: a map fed frame by frame reallocates rarely
+        for (void* q : {(void*)g->pts_alt, (void*)g->keys_alt, (void*)g->normals_alt}) if (q) (void)hipFree(q);
+        g->pts_alt = nullptr; g->keys_alt = nullptr; g->normals_alt = nullptr; g->cap_alt = 0;
+        const size_t cap = std::max(total, g->cap + g->cap / 2);
+        hipError_t e = hipMalloc(&g->pts_alt, cap * sizeof(GridPoint));
+        if (e == hipSuccess) e = hipMalloc(&g->keys_alt, cap * 8);
+        if (e == hipSuccess && g->have_normals) e = hipMalloc(&g->normals_alt, cap * 16);
+        if (e != hipSuccess) {
+            run.release();
+            return pcp_fail("buffers for a map of %zu points: %s", cap, hipGetErrorString(e));
+        }
+        g->cap_alt = cap;
+    }
+    hipLaunchKernelGGL(k_merge_old, dim3(blocks_for(g->n, 256)), dim3(256), 0, s, g->keys, g->n, run.keys, m, g->pts, g->normals,
+                       g->pts_alt, g->keys_alt, g->normals_alt);
+    hipLaunchKernelGGL(k_merge_new, dim3(blocks_for(m, 256)), dim3(256), 0, s, g->keys, g->n, run.keys, m, run.pts, run.normals,
+                       g->pts_alt, g->keys_alt, g->normals_alt);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    run.release();
+    if (e != hipSuccess) return pcp_fail("merging %zu points into the map: %s", m, hipGetErrorString(e));
+    std::swap(g->pts, g->pts_alt);
+    std::swap(g->keys, g->keys_alt);
+    std::swap(g->normals, g->normals_alt);
+    std::swap(g->cap, g->cap_alt);
+    g->n = total;
+    int lo[3], hi[3];
+    for (int a = 0; a < 3; ++a) { lo[a] = std::min(g->lo[a], run.lo[a]); hi[a] = std::max(g->hi[a], run.hi[a]); }
+    set_bounds(g, lo, hi);
+    return install_table(g);
 }
 
 static int check_build_args(pcp_grid* g, const double* xyz, size_t n, double cell) {
@@ -1399,6 +1579,75 @@ int pcp_grid_build_slab(pcp_grid* g, const double* xyz, size_t n, double cell, c
     cleanup();
     if (!rc && n_kept) *n_kept = kept;
     return rc;
+}
+
+static int append_host(pcp_grid* g, const double* xyz, size_t n, const float* normals_xyzw, long long first_id,
+                       bool slab, double own_cell, unsigned long long lo, unsigned long long hi, size_t* n_kept) {
+    if (!g) return pcp_fail("null grid");
+    if (!(g->cell > 0.0)) return pcp_fail("the grid has no cell size yet: call pcp_grid_build first (an empty map will do)");
+    if (n && !xyz) return pcp_fail("xyz is null");
+    if (n >= (1ull << 31)) return pcp_fail("%zu points exceed the 2^31 limit of one grid", n);
+    if (first_id < 0) return pcp_fail("first_id must not be negative");
+    if (n_kept) *n_kept = 0;
+    if (n == 0) return 0;
+    PCP_CHECK(hipSetDevice(g->device));
+    hipStream_t s = g->stream;
+    PCP_CHECK(hipStreamSynchronize(s));
+    double *d_xyz = nullptr, *d_keep = nullptr;
+    float4 *d_nrm = nullptr, *d_nkeep = nullptr;
+    unsigned *d_ids = nullptr, *d_counts = nullptr;
+    int* d_bad = nullptr;
+    auto cleanup = [&]() {
+        for (void* q : {(void*)d_xyz, (void*)d_keep, (void*)d_nrm, (void*)d_nkeep, (void*)d_ids, (void*)d_counts, (void*)d_bad})
+            if (q) (void)hipFree(q);
+    };
+    hipError_t e = hipMalloc(&d_xyz, n * 24);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_xyz, xyz, n * 24, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess && normals_xyzw) {
+        e = hipMalloc(&d_nrm, n * 16);
+        if (e == hipSuccess) e = hipMemcpyAsync(d_nrm, normals_xyzw, n * 16, hipMemcpyHostToDevice, s);
+    }
+    int rc = 0;
+    size_t kept = n;
+    const double* use_xyz = d_xyz;
+    const float4* use_nrm = d_nrm;
+    const unsigned* use_ids = nullptr;
+    if (e == hipSuccess && slab) {          // this rank's share: own cells plus the one-cell halo, as pcp_grid_build_slab
+        e = hipMalloc(&d_keep, n * 24);
+        if (e == hipSuccess) e = hipMalloc(&d_ids, n * 4);
+        if (e == hipSuccess) e = hipMalloc(&d_counts, compact_count_elems(n) * 4);
+        if (e == hipSuccess) e = hipMalloc(&d_bad, 4);
+        if (e == hipSuccess) e = hipMemsetAsync(d_bad, 0, 4, s);
+        if (e == hipSuccess && d_nrm) e = hipMalloc(&d_nkeep, n * 16);
+        unsigned k = 0;
+        int bad = 0;
+        if (e == hipSuccess) {
+            compact_ordered(s, InSlab{d_xyz, own_cell, lo, hi, d_bad}, EmitKept{d_xyz, d_nrm, d_keep, d_nkeep, d_ids}, n, d_counts);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipMemcpyAsync(&k, d_counts + compact_tiles(n), 4, hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        if (e == hipSuccess && bad) rc = pcp_fail("map coordinates must be finite and within 2^20 partition cells of the origin");
+        kept = k;
+        use_xyz = d_keep; use_nrm = d_nkeep; use_ids = d_ids;
+    }
+    if (e != hipSuccess) rc = pcp_fail("uploading the points failed: %s", hipGetErrorString(e));
+    if (!rc) rc = append_device(g, use_xyz, use_nrm, use_ids, first_id, kept);
+    cleanup();
+    if (!rc && n_kept) *n_kept = kept;
+    return rc;
+}
+
+int pcp_grid_append(pcp_grid* g, const double* xyz, size_t n, const float* normals_xyzw, long long first_id) {
+    return append_host(g, xyz, n, normals_xyzw, first_id, false, 1.0, 0, 0, nullptr);
+}
+
+int pcp_grid_append_slab(pcp_grid* g, const double* xyz, size_t n, const float* normals_xyzw, double own_cell,
+                         unsigned long long lo, unsigned long long hi, long long first_id, size_t* n_kept) {
+    if (!(own_cell > 0.0)) return pcp_fail("partition cell size must be positive");
+    if (lo > hi) return pcp_fail("owned key range is empty");
+    return append_host(g, xyz, n, normals_xyzw, first_id, true, own_cell, lo, hi, n_kept);
 }
 
 int pcp_grid_partition(int device, const double* xyz, size_t n, double own_cell, int world, unsigned long long* cuts) {
@@ -1484,7 +1733,7 @@ int pcp_grid_estimate_normals(pcp_grid* g, double radius, int min_points, const 
     if (cells > 3.0)
         return pcp_fail("radius %g spans more than 3 cells of edge %g: build the grid with larger cells", radius, g->cell);
     PCP_CHECK(hipSetDevice(g->device));
-    if (!g->normals) PCP_CHECK(hipMalloc(&g->normals, g->n * 16));
+    if (!g->normals) PCP_CHECK(hipMalloc(&g->normals, std::max(g->cap, g->n) * 16));
     unsigned* d_counts = nullptr;
     if (counts) PCP_CHECK(hipMalloc(&d_counts, g->n * 4));
     PcaArgs A;
@@ -1504,6 +1753,7 @@ int pcp_grid_estimate_normals(pcp_grid* g, double radius, int min_points, const 
     if (d_counts) (void)hipFree(d_counts);
     if (e != hipSuccess) return pcp_fail("estimating normals failed: %s", hipGetErrorString(e));
     g->have_normals = true;
+    g->normals_estimated = true;
     return 0;
 }
 

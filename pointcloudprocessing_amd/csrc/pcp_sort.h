@@ -199,4 +199,30 @@ inline void radix_sort_pairs(hipStream_t stream, unsigned long long* keys0, unsi
     *vals_out = vin;
 }
 
+// The same for keys of which only the bits set in `varying` can differ between any two of them:
+// an 8-bit digit in which no key differs leaves the order as it is, so its pass is skipped.  Returns
+// the number of passes made.
+inline int radix_sort_pairs_varying(hipStream_t stream, unsigned long long* keys0, unsigned long long* keys1,
+                                    unsigned* vals0, unsigned* vals1, size_t n, unsigned long long varying, unsigned* hist,
+                                    unsigned* totals, unsigned* base, unsigned long long** keys_out, unsigned** vals_out) {
+    const int nblk = (int)((n + RS_TILE - 1) / RS_TILE);
+    unsigned long long *kin = keys0, *kout = keys1;
+    unsigned *vin = vals0, *vout = vals1;
+    int passes = 0;
+    for (int p = 0; p < 8 && n > 0; ++p) {
+        const int shift = 8 * p;
+        if (((varying >> shift) & 0xFFull) == 0) continue;
+        hipLaunchKernelGGL(k_rs_hist, dim3(nblk), dim3(RS_THREADS), 0, stream, kin, n, shift, hist, nblk);
+        hipLaunchKernelGGL(k_rs_scan, dim3(256), dim3(256), 0, stream, hist, nblk, totals);
+        hipLaunchKernelGGL(k_rs_base, dim3(1), dim3(256), 0, stream, totals, base);
+        hipLaunchKernelGGL(k_rs_scatter, dim3(nblk), dim3(RS_THREADS), 0, stream, kin, vin, n, shift, hist, base, nblk, kout, vout);
+        std::swap(kin, kout);
+        std::swap(vin, vout);
+        ++passes;
+    }
+    *keys_out = kin;
+    *vals_out = vin;
+    return passes;
+}
+
 }  // namespace pcp

@@ -1,0 +1,36 @@
+"""The accumulated map as the destination of the Voxelizer's staged voxels.
+
+The reference's Voxelizer hands the points of every voxel it stages (full, or static by its Bayes filter:
+VoxelStage.glsl:41-60, :201-315) to a VoxelManager, whose frameVoxelized draws them (Voxelizer.py:130-133,
+VoxelManager.py:31-45).  MapSink takes that manager's place: the staged points join a cell grid on the
+device (CellGrid.append / MapRegistration.ingest, no rebuild), which is the map later scans are registered
+against -- the voxel map the Voxelizer accumulates and the map scan-to-map searches become one structure.
+"""
+import numpy as np
+
+
+class MapSink:
+    needs_renderer = False            # Voxelizer._hand_off feeds it without a renderer
+
+    def __init__(self, target):
+        """target: a CellGrid (append) or a scan_to_map.MapRegistration (ingest: routed by key range)."""
+        self.target = target
+        self._batch = []
+        self.points_fed = 0
+        self.voxels_fed = 0
+
+    def frameVoxelized(self, voxel_points, colors, separate_colors):
+        """VoxelManager.frameVoxelized's signature; the colours are the renderer's business, not the map's."""
+        if len(voxel_points):
+            self._batch.append(np.asarray(voxel_points, dtype=np.float64)[:, :3])
+            self.voxels_fed += 1
+
+    def flush(self):
+        """One append per dispatch: the staged voxels of a frame go in together."""
+        if not self._batch:
+            return 0
+        pts = np.ascontiguousarray(np.concatenate(self._batch, axis=0))
+        self._batch = []
+        (self.target.ingest if hasattr(self.target, "ingest") else self.target.append)(pts)
+        self.points_fed += len(pts)
+        return len(pts)

@@ -151,6 +151,12 @@ class HipMapBackend:
         torch.cuda.synchronize(dev)
         self._check(self._lib.pcp_grid_set_stream(self.grid._g, self.stream.cuda_stream))
 
+    def append(self, points, normals, first_id, slab=None):
+        slab3 = None if slab is None else (self.own_cell, slab[0], slab[1])
+        kept = self.grid.append(points, normals=normals, first_id=first_id, slab=slab3)
+        self.held = self.grid.held
+        return kept
+
     def stream_context(self):
         return self._torch.cuda.stream(self.stream)
 
@@ -250,6 +256,19 @@ class MapRegistration:
             else:
                 self.backend.build(pts, normals, self.cell, nn_cell)
         self.backend.set_owned(lo, hi)
+        self.total_points = len(np.asarray(map_points))
+
+    def ingest(self, points, normals=None):
+        """New map points (e.g. the voxels a Voxelizer staged this frame, through map_sink.MapSink) join the
+        resident map without a rebuild.  Every rank is handed the same batch and keeps the points in or next
+        to its key range (the routing of the partitioned map: no exchange, the ranges were fixed when the map
+        was split); ids continue the numbering of the whole map.  Returns the points this rank kept."""
+        pts = np.asarray(points, dtype=np.float64)[:, :3]
+        lo, hi = self.ranges[self.rank]
+        kept = self.backend.append(pts, normals, self.total_points, slab=(lo, hi) if self.world > 1 else None)
+        self.total_points += len(pts)
+        self.slab_points += kept
+        return kept
 
     def _all_reduce(self, tile):
         if self.comm is not None:

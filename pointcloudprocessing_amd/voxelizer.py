@@ -121,11 +121,17 @@ class Voxelizer:
         self._hand_off(voxels_to_render)
 
     def _hand_off(self, voxels_to_render):
-        if self.renderer is None or self.voxman is None:
+        """:130-133 -- the points of every voxel staged by this dispatch go to the voxel manager.  The
+        reference's manager draws them (VoxelManager.frameVoxelized :31-45, needs the renderer); a manager
+        that says `needs_renderer = False` (map_sink.MapSink: the staged points accumulate in a cell grid
+        that scans are registered against) is fed without one."""
+        if self.voxman is None or (self.renderer is None and getattr(self.voxman, "needs_renderer", True)):
             return
         for v_slice in voxels_to_render:
             points, colors = self.getStoredPointsFromVoxelDataSlice(v_slice)
             self.voxman.frameVoxelized(points, colors, self.separate_colors)
+        if hasattr(self.voxman, "flush"):
+            self.voxman.flush()
 
     def refreshVoxelData(self):
         if not self.last_run_realloc:

@@ -24,6 +24,14 @@ def morton(c):
     return _spread(c[:, 0]) | (_spread(c[:, 1]) << np.uint64(1)) | (_spread(c[:, 2]) << np.uint64(2))
 
 
+def cell_keys_abs(points, cell):
+    """The grid's cell key in NumPy: absolute cell coordinates floor(p / cell), zig-zag per axis
+    (0, -1, 1, -2, ... -> 0, 1, 2, 3, ...), bits interleaved."""
+    c = np.floor(np.asarray(points) / cell).astype(np.int64)
+    z = np.where(c >= 0, 2 * c, -2 * c - 1).astype(np.uint64)
+    return morton(z), c
+
+
 def assert_same_neighbours(a, q, idx, dist, ref_idx, ref_dist):
     """Equal distances everywhere; indices may differ from the KD-tree's only on exact ties, where
     the grid returns the lowest index."""
@@ -57,15 +65,16 @@ def test_build_sorts_by_cell_key_and_keeps_every_point(frames, grid0):
     ids, xyz = grid0.sorted_points()
     assert info["points"] == len(a) and np.array_equal(np.sort(ids), np.arange(len(a)))
     assert np.array_equal(xyz, a[ids])
-    c = np.floor(a / 0.5).astype(np.int64)
-    rel = (c - c.min(axis=0))[ids]
-    keys = morton(rel)
+    keys, c = cell_keys_abs(a[ids], 0.5)
     assert np.all(np.diff(keys.astype(np.int64)) >= 0)
     same = np.diff(keys.astype(np.int64)) == 0
     assert np.all(np.diff(ids)[same] > 0)                    # stable: original order inside a cell
     assert info["cells"] == len(np.unique(keys))
     assert info["extent"] == (c.max(axis=0) - c.min(axis=0) + 1).tolist()
-    assert info["sort_passes"] == -(-3 * int(np.ceil(np.log2(max(info["extent"])))) // 8)
+    # the frame straddles the origin in every axis: zig-zag values up to 2 * max|c|, their bits interleaved,
+    # one radix pass per 8 key bits that can vary
+    bits_needed = int(np.ceil(np.log2(2 * np.abs(c).max() + 2)))
+    assert info["sort_passes"] == -(-3 * bits_needed // 8)
 
 
 def test_query_equals_reference_kdtree_on_kitti(frames, grid0):
@@ -300,6 +309,163 @@ def test_map_registration_driver_equals_the_fused_loop_bitwise(mode):
     finally:
         g.cleanup()
         reg.close()
+
+
+# ------------------------------------------------------------------------------ a map that accumulates (pcp_grid_append)
+def _same_grid(g_inc, g_all, queries):
+    ids_i, xyz_i = g_inc.sorted_points()
+    ids_a, xyz_a = g_all.sorted_points()
+    assert np.array_equal(ids_i, ids_a) and np.array_equal(xyz_i, xyz_a)            # same order, entry by entry
+    ii, ia = g_inc.info(), g_all.info()
+    assert (ii["points"], ii["cells"], ii["extent"]) == (ia["points"], ia["cells"], ia["extent"])
+    d_i, i_i = g_inc.query(queries)
+    d_a, i_a = g_all.query(queries)
+    assert np.array_equal(i_i, i_a) and np.array_equal(bits64(d_i), bits64(d_a))
+    d_i, i_i = g_inc.query(queries, distance_upper_bound=0.3)
+    d_a, i_a = g_all.query(queries, distance_upper_bound=0.3)
+    assert np.array_equal(i_i, i_a) and np.array_equal(bits64(d_i), bits64(d_a))
+
+
+def test_appending_frames_equals_building_the_whole(frames):
+    """Frame 1 ingested into the grid of frame 0 (moved a little, and far away once so that the bounding box
+    grows on the negative and the positive side) = the grid built from all points at once."""
+    a, b = frames
+    far = b[:5000] + np.array([-700.0, 35.0, 900.0])
+    batches = [a, b + np.array([0.3, 0.0, 0.1]), far, a[::3] * np.array([1.0, 1.0, -1.0])]
+    g_inc = CellGrid(batches[0], cell=0.5)
+    g_all = CellGrid(np.concatenate(batches), cell=0.5)
+    try:
+        for extra in batches[1:]:
+            g_inc.append(extra)
+        _same_grid(g_inc, g_all, np.concatenate([b[::11], far[::7] + 0.05]))
+        # starting from an empty map, and a batch of one point
+        g_inc.rebuild(np.zeros((0, 3)), cell=0.5)
+        for extra in batches + [np.array([[1e3, -2.0, 1e3]])]:
+            g_inc.append(extra)
+        g_all.rebuild(np.concatenate(batches + [np.array([[1e3, -2.0, 1e3]])]), cell=0.5)
+        _same_grid(g_inc, g_all, b[::29])
+    finally:
+        g_inc.cleanup()
+        g_all.cleanup()
+
+
+def test_appending_with_normals_and_the_rules_around_them(frames):
+    a, b = frames[0][::5], frames[1][::5]
+    rng = np.random.default_rng(2)
+    na, nb = rng.normal(size=(len(a), 3)).astype(np.float32), rng.normal(size=(len(b), 3)).astype(np.float32)
+    g_inc = CellGrid(a, cell=0.5, normals=na)
+    g_all = CellGrid(np.concatenate([a, b]), cell=0.5, normals=np.concatenate([na, nb]))
+    try:
+        with pytest.raises(RuntimeError, match="normals"):
+            g_inc.append(b)                                    # the caller's normals cannot be left out
+        g_inc.append(b, normals=nb)
+        src = b[::3] + 0.01
+        g_inc.set_source(src)
+        g_all.set_source(src)
+        Hi, bi = g_inc.ls(1, 0.4)
+        Ha, ba = g_all.ls(1, 0.4)
+        assert np.array_equal(bits(Hi), bits(Ha)) and np.array_equal(bits(bi), bits(ba))     # the plane tiles see the same normals
+        # estimated normals are of the map as it was: an append drops them
+        g_inc.rebuild(a, cell=0.5)
+        g_inc.estimate_normals(0.5)
+        g_inc.append(b)
+        g_inc.set_source(src)
+        with pytest.raises(RuntimeError, match="normals"):
+            g_inc.ls(1, 0.4)
+    finally:
+        g_inc.cleanup()
+        g_all.cleanup()
+
+
+def test_ten_million_point_map_grown_by_ingests_equals_its_build(frames):
+    """One GPU's share of the accumulated-map configuration: 100 sweeps along a drive (12.3 M points) fed in ten
+    ingests of ten sweeps, against the build of the concatenation; then a scan registered on both."""
+    a, b = frames
+    rng = np.random.default_rng(7)
+    sweeps = [a + np.array([0.05 * k, 0.0, -0.33 * k]) + rng.normal(0, 0.004, a.shape) for k in range(100)]
+    batches = [np.concatenate(sweeps[k:k + 10]) for k in range(0, 100, 10)]
+    whole = np.concatenate(batches)
+    assert len(whole) > 10_000_000
+    g_inc = CellGrid(batches[0], cell=0.25)
+    g_all = CellGrid(whole, cell=0.25)
+    try:
+        for extra in batches[1:]:
+            g_inc.append(extra)
+        scan = b + np.array([0.02, 0.0, -16.5])
+        _same_grid(g_inc, g_all, scan[::3])
+        runs = []
+        for g in (g_inc, g_all):
+            g.set_source(scan)
+            runs.append(g.icp_run(0, 0.25, max_iter=5))
+        assert np.array_equal(bits(runs[0][0]), bits(runs[1][0])) and np.array_equal(bits(runs[0][2]), bits(runs[1][2]))
+    finally:
+        g_inc.cleanup()
+        g_all.cleanup()
+
+
+def test_staged_voxels_of_the_voxelizer_accumulate_in_the_map(frames):
+    """Voxelizer -> MapSink -> CellGrid: what the reference's Voxelizer hands to its VoxelManager for drawing
+    (Voxelizer.py:130-133) is the map here.  Every staged point is in the grid afterwards, nothing else is."""
+    from pointcloudprocessing_amd import ComputeShader, MapSink, Voxelizer
+    a, b = frames
+    cs = ComputeShader(maxPointsPerCloud=200000, maxScans=100)
+    grid = CellGrid(np.zeros((0, 3)), cell=0.5)
+    sink = MapSink(grid)
+    seen = []
+
+    class Recording(MapSink):
+        def frameVoxelized(self, pts, colors, separate):
+            seen.append(np.asarray(pts, dtype=np.float64))
+            MapSink.frameVoxelized(self, pts, colors, separate)
+
+    sink = Recording(grid)
+    vox = Voxelizer(cs, None, voxman=sink)
+    try:
+        vox.init(0.5)
+        vox.separate_colors, vox.filter_outliers = False, False
+        for k in range(4):                                     # the same street seen four times: voxels fill up and get staged
+            vox.addPoints(a + np.array([0.0, 0.0, -0.33 * k]), None)
+        vox.stageAllRemaningVoxels()
+        staged = np.concatenate(seen)
+        assert sink.points_fed == len(staged) > 100000 and grid.info()["points"] == len(staged)
+        ids, xyz = grid.sorted_points()
+        assert np.array_equal(np.sort(ids), np.arange(len(staged))) and np.array_equal(xyz, staged[ids])
+        d, i = grid.query(staged[::17])
+        assert np.all(d == 0.0)
+        # and a scan registers against the accumulated map
+        grid.set_source(b[::2])
+        dx, conv, _ = grid.icp_run(0, 0.5, max_iter=6)
+        assert len(dx) == 6 and np.abs(dx[-1]).max() < np.abs(dx[0]).max()
+    finally:
+        vox.cleanup()
+        grid.cleanup()
+        cs.cleanup()
+
+
+def test_ingest_routed_by_key_range_equals_the_slab_of_the_whole(frames):
+    """Two ranks' shares, one after the other on this GPU: each rank's slab grown by ingests (every rank is handed
+    the same batch and keeps its part) equals its slab of the whole map."""
+    from pointcloudprocessing_amd import scan_to_map as S
+    a, b = frames
+    first, more = a, [b + np.array([0.3, 0.0, 0.1]), a[::2] + np.array([25.0, 0.0, -40.0])]
+    whole = np.concatenate([first] + more)
+    ranges = S.HipMapBackend(0).partition(whole, 1.0, 2)
+    for rank in range(2):
+        reg_inc = S.MapRegistration(first, 1.0, rank=rank, world=2, nn_cell=0.5)
+        reg_inc.ranges = ranges                      # the cut of the WHOLE map: fixed before the first ingest
+        reg_inc.backend.build(first, None, 1.0, 0.5, slab=ranges[rank])
+        reg_inc.backend.set_owned(*ranges[rank])
+        reg_inc.slab_points = reg_inc.backend.held
+        reg_all = S.MapRegistration(whole, 1.0, rank=rank, world=2, nn_cell=0.5)
+        try:
+            assert reg_all.ranges == ranges
+            for extra in more:
+                reg_inc.ingest(extra)
+            assert reg_inc.slab_points == reg_all.slab_points and reg_inc.total_points == len(whole)
+            _same_grid(reg_inc.backend.grid, reg_all.backend.grid, b[::13])
+        finally:
+            reg_inc.close()
+            reg_all.close()
 
 
 @pytest.mark.parametrize("mode", [0, 1])
