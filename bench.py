@@ -153,8 +153,8 @@ def run_sequence(args, rank, world, device, barrier):
 
     # latency of one pair from its raw bytes in host memory to its steps on the host, nothing else in flight
     two = [pinned[0], pinned[1]]
-    lat = []
-    for _ in range(13):
+    lat = [0.0] * 4
+    for _ in range(0 if args.no_latency else 13):
         c0 = time.perf_counter()
         pipe.collect(pipe.submit(two, point_to_plane=True, iterations=MAX_ITER, tol=TOL))
         lat.append(time.perf_counter() - c0)
@@ -366,6 +366,8 @@ def main():
     ap.add_argument("--workload", choices=("sequence", "moved-copy"), default="sequence")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
+    ap.add_argument("--no-latency", action="store_true",
+                    help="skip the single-pair latency legs (profiling passes: every launch of the fused kernel then is a full step's)")
     args = ap.parse_args()
 
     import torch
@@ -400,7 +402,7 @@ def main():
     total_pairs = args.pairs * world * args.steps
 
     single, cpu, more = None, None, {}
-    if rank == 0:
+    if rank == 0 and not args.no_latency:
         # one registration alone on the GPU, target kept prepared: upload of the 3 MB float64 source, loop, fetch
         a, b = lidar.frame_from_raw(raws[0][:, :3]), lidar.frame_from_raw(raws[1][:, :3])
         cs = ComputeShader(maxPointsPerCloud=max(len(a), len(b)), maxScans=100, device=device)
@@ -455,8 +457,11 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": res["traffic"],
                          "avg_launch_us": res["avg_launch_s"] * 1e6, "launches_timed": res["ls_launches"],
                          "algorithmic_bytes_per_launch": res["alg_bytes"],
-                         "limited_by": "not HBM: dependent 16-byte gathers served by L1/L2 (vector-memory address path ~70 % busy, "
-                                       "vector ALU ~75 % busy, waves wait ~70 % of their life; counters under profiles/)"},
+                         "limited_by": "not HBM: chains of dependent 16-byte gathers served by L1/L2. Counters of this workload "
+                                       "(profiles/r02_seq_pmc_*.csv): texture-address units 77 % busy on average and 89 % on the busiest, "
+                                       "vector ALU 78 % busy, waves waiting 71 % of their life, L2 hit rate 86 %; `traffic` (L2 misses: "
+                                       "every launch streams its float64 working copy, hints and each pair's target once) is 3x the "
+                                       "algorithmic bytes, which count a target once per pair, not once per launch"},
             "cpu_baseline": cpu,
             "single_pair": single,
         }
