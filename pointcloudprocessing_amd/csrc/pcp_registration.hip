@@ -268,6 +268,7 @@ struct LsArgs {
     const float4* normals; const float4* b32; const double* b_in; double* b64; IcpState* st;
     int n_b, debug;
     float* hint; float* partials; float* tiles;
+    int skip_store_iter;      // the dispatch (st->iter) whose moved points nobody will read: not written back (-1 = none)
 };
 
 template <int MODE, bool F64SRC>
@@ -304,7 +305,7 @@ __device__ __forceinline__ void ls_body(const LsArgs& A, char* smem, const unsig
                 const double nz = ((st->R[6] * px + st->R[7] * py) + st->R[8] * pz) - st->t[2];
                 px = nx; py = ny; pz = nz;
             }
-            if (st->pending || first) {
+            if ((st->pending || first) && st->iter != A.skip_store_iter) {
                 b64[3 * (size_t)i + 0] = px; b64[3 * (size_t)i + 1] = py; b64[3 * (size_t)i + 2] = pz;
             }
             q = make_float4((float)px, (float)py, (float)pz, 0.0f);
@@ -397,7 +398,7 @@ __global__ void __launch_bounds__(256) k_ls_quad(const LsArgs A) {
             const double nz = ((st->R[6] * px + st->R[7] * py) + st->R[8] * pz) - st->t[2];
             px = nx; py = ny; pz = nz;
         }
-        moved = st->pending || first;
+        moved = (st->pending || first) && st->iter != A.skip_store_iter;
         q = make_float4((float)px, (float)py, (float)pz, 0.0f);
     } else if (in) {
         q = A.b32[i];
@@ -659,6 +660,7 @@ LsArgs ls_args(const pcp_ctx* c, int debug, float* tiles) {
     A.normals = c->normals; A.b32 = c->b32; A.b_in = c->b_in; A.b64 = c->b64; A.st = c->state;
     A.n_b = c->n_b; A.debug = debug;
     A.hint = c->hint; A.partials = c->partials; A.tiles = tiles;
+    A.skip_store_iter = -1;
     return A;
 }
 

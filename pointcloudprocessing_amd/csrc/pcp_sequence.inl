@@ -172,6 +172,7 @@ struct SeqDescribe {
     unsigned* const* ends; int2* const* scan;
     LsArgs* ls; FinishArgs* fin; PrepArgs* prep; int* flags;
     int n_pairs, max_scans, pad_lines;
+    int last_iter;       // the run's last dispatch: the points it moves are never read (poses come from the steps)
 };
 
 __global__ void k_seq_describe(const SeqDescribe D) {
@@ -202,6 +203,7 @@ __global__ void k_seq_describe(const SeqDescribe D) {
     }
     LsArgs& L = D.ls[p];
     L.n_a = flag ? 0 : (int)n_a; L.n_b = flag ? 0 : (int)n_b; L.Z = Z; L.Zs = Zs;
+    L.skip_store_iter = D.last_iter;
     D.fin[p].n1 = flag ? 0 : (int)((n_b + 63) / 64);
     D.prep[p].n_a = flag ? 0 : (int)n_a; D.prep[p].Z = Z;
     D.flags[p] = flag;
@@ -421,6 +423,7 @@ int pcp_seq_submit(pcp_seq* s, const float* const* raw_xyzi, const int* n_raw, i
     D.n_pts = s->n_pts; D.ring_counts = s->ring_counts; D.ring_stride = s->stride; D.ring_tiles = s->tiles;
     D.ends = s->ends_dev; D.scan = s->scan_dev; D.ls = s->ls_dev; D.fin = s->fin_dev; D.prep = s->prep_dev; D.flags = s->flags_dev;
     D.n_pairs = P; D.max_scans = s->max_scans; D.pad_lines = (mode == PCP_MODE_PLANE) ? 1 : 0;
+    D.last_iter = max_iter - 1;
     hipLaunchKernelGGL(k_seq_describe, dim3(cdiv(P, 64)), dim3(64), 0, q, D);
     PCP_CHECK(hipGetLastError());
     // origin as uploaded: np.resize(origin, (4,)) repeats, [ox, oy, oz, ox] (ComputeShader.py:436-437); it sits in the

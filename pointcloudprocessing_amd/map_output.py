@@ -94,6 +94,18 @@ def save_arena_ply(path_to_save_to, memory_manager):
     return save_ply(path_to_save_to, memory_manager.points[:memory_manager.getMaxPointIndex()])
 
 
+def save_grid_ply(path_to_save_to, grid, colour=(1.0, 1.0, 1.0)):
+    """The accumulated map, as it lies on the device in a CellGrid (fed by map_sink.MapSink from the voxels the
+    Voxelizer staged), written in the reference's PLY format (savePointcloudPly :13-57) in the order the points
+    were fed.  The reference writes its render arena, which holds the same staged points; here the map itself is
+    the source."""
+    ids, xyz = grid.sorted_points()
+    pts = np.empty((len(ids), 6), dtype=np.float64)
+    pts[ids, :3] = xyz                                  # back into feeding order
+    pts[:, 3:] = np.asarray(colour, dtype=np.float64)
+    return save_ply(path_to_save_to, pts)
+
+
 def read_ply_ascii(path):
     """PointcloudHandler.tryReadAsciPly (:60-113): (N, 6) float64, colours back in [0, 1]; None when the
     file is not text."""

@@ -403,7 +403,7 @@ def test_ten_million_point_map_grown_by_ingests_equals_its_build(frames):
         g_all.cleanup()
 
 
-def test_staged_voxels_of_the_voxelizer_accumulate_in_the_map(frames):
+def test_staged_voxels_of_the_voxelizer_accumulate_in_the_map(frames, tmp_path):
     """Voxelizer -> MapSink -> CellGrid: what the reference's Voxelizer hands to its VoxelManager for drawing
     (Voxelizer.py:130-133) is the map here.  Every staged point is in the grid afterwards, nothing else is."""
     from pointcloudprocessing_amd import ComputeShader, MapSink, Voxelizer
@@ -432,6 +432,10 @@ def test_staged_voxels_of_the_voxelizer_accumulate_in_the_map(frames):
         assert np.array_equal(np.sort(ids), np.arange(len(staged))) and np.array_equal(xyz, staged[ids])
         d, i = grid.query(staged[::17])
         assert np.all(d == 0.0)
+        # the map leaves the device in the reference's PLY format, in feeding order
+        from pointcloudprocessing_amd.map_output import read_ply_ascii, save_grid_ply
+        back = read_ply_ascii(save_grid_ply(str(tmp_path / "map"), grid))
+        assert back.shape == (len(staged), 6) and np.allclose(back[:, :3], staged, atol=6e-7) and np.all(back[:, 3:] == 1.0)
         # and a scan registers against the accumulated map
         grid.set_source(b[::2])
         dx, conv, _ = grid.icp_run(0, 0.5, max_iter=6)

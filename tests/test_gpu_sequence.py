@@ -143,6 +143,34 @@ def test_pipeline_equals_the_pair_by_pair_device_path(plane, iterations):
         pinned.close()
 
 
+def test_pipeline_about_a_non_zero_origin():
+    """Scan lines and unit vectors about an origin with x != 0: the [ox, oy, oz, ox] upload (ComputeShader.py:436-437)
+    is live in every dot product; the pipeline still equals the pair-by-pair path bit for bit."""
+    from pointcloudprocessing_amd import PinnedFrames, SequencePipeline
+    from pointcloudprocessing_amd.frame import DeviceFrame, register_frames
+    raws = [_raw4(r) for r in kitti_sequence_raw()[:4]]
+    origin = np.array([0.35, -0.05, 0.2])
+    pipe = SequencePipeline(max_frames=4, max_points=131072)
+    cs = ComputeShader(maxPointsPerCloud=131072, maxScans=100)
+    fa, fb = DeviceFrame(131072), DeviceFrame(131072)
+    try:
+        steps, n_pts = pipe.collect(pipe.submit(raws, origin=origin, iterations=5))
+        for p in range(3):
+            fa.decode(raws[p]); fb.decode(raws[p + 1])
+            _, dx, conv = register_frames(cs, fa, fb, origin, point_to_plane=True, iterations=5)
+            assert conv == steps[p][1] and np.array_equal(bits(dx), bits(steps[p][0])), p
+        # and back to the zero origin on the same pipeline (the descriptors' origin is refreshed)
+        steps0, _ = pipe.collect(pipe.submit(raws, iterations=5))
+        fa.decode(raws[0]); fb.decode(raws[1])
+        _, dx, conv = register_frames(cs, fa, fb, np.zeros(3), point_to_plane=True, iterations=5)
+        assert np.array_equal(bits(dx), bits(steps0[0][0])) and not np.array_equal(bits(dx), bits(steps[0][0]))
+    finally:
+        fa.cleanup()
+        fb.cleanup()
+        cs.cleanup()
+        pipe.close()
+
+
 def test_pipeline_reports_pairs_that_cannot_run():
     from pointcloudprocessing_amd import PcpError, SequencePipeline
     raws = [_raw4(r) for r in kitti_sequence_raw()[:2]]
