@@ -482,12 +482,13 @@ int pcp_seq_collect(pcp_seq* s, int ticket, float* dx_trace, int dx_stride_iters
     if (!s) return pcp_fail("null sequence");
     const int slot = ticket & 1;
     if (ticket < 0 || !s->in_flight[slot] || s->ticket_of[slot] != ticket) return pcp_fail("ticket %d is not in flight", ticket);
+    if (dx_trace && dx_stride_iters < s->iters[slot])      // before the slot is given up: the caller can come again
+        return pcp_fail("dx_trace holds %d steps per pair, the run made up to %d", dx_stride_iters, s->iters[slot]);
     PCP_CHECK(hipSetDevice(s->device));
     PCP_CHECK(hipEventSynchronize(s->finished[slot]));
     const int P = s->in_flight[slot];
     s->in_flight[slot] = 0;
     const SeqRecord* rec = s->rec_host[slot];
-    if (dx_trace && dx_stride_iters < s->iters[slot]) return pcp_fail("dx_trace holds %d steps per pair, the run made up to %d", dx_stride_iters, s->iters[slot]);
     int bad = -1;
     s->last_longest = 0;
     s->last_points = 0;
