@@ -447,6 +447,16 @@ int pcp_seq_destroy(pcp_seq* seq);
 int pcp_seq_submit(pcp_seq* seq, const float* const* raw_xyzi, const int* n_raw, int n_frames, float min_range,
                    const double* R9, const double* origin3, int mode, int max_iter, float tol, int full_iter,
                    int* ticket);
+/* pcp_seq_submit with a placement per frame, what EnvironmentConstructor.calculateTransition_imu (:154-265) does to a
+ * frame before it is registered: placements holds 12 float64 per frame, a rotation Q (row-major) and an offset g.
+ * Frame f becomes Q_f (R9 p) -- the IMU attitude of :169, a second, separately rounded product like
+ * (imu_rotation @ cloud.T).T -- for its scan lines, its normals and as the target of pair f; as the source of pair
+ * f - 1 it is that cloud + g_f (the IMU's guess of the motion since frame f - 1, :200-209), added in float64 when the
+ * first dispatch reads the frame.  The steps returned are those of full_pt2pl(target, placed source): the pose of
+ * the placed source against the target, the guess not included.  placements == NULL is pcp_seq_submit. */
+int pcp_seq_submit_placed(pcp_seq* seq, const float* const* raw_xyzi, const int* n_raw, int n_frames, float min_range,
+                          const double* R9, const double* origin3, const double* placements, int mode, int max_iter,
+                          float tol, int full_iter, int* ticket);
 /* Wait for a submission and fetch its results, pair p = (frame p <- frame p + 1): dx_trace receives
  * dx_stride_iters x 6 floats per pair (the steps, zero beyond iters[p]), iters / converged one int per
  * pair, n_points (or NULL) the points each of the n_frames frames kept.  Fails (after filling the outputs)

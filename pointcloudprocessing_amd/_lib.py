@@ -126,6 +126,8 @@ SIGNATURES = {
     "pcp_seq_destroy": (C.c_int, [C.c_void_p]),
     "pcp_seq_submit": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), _i32p, C.c_int, C.c_float, _f64p, _f64p, C.c_int, C.c_int,
                                  C.c_float, C.c_int, _i32p]),
+    "pcp_seq_submit_placed": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), _i32p, C.c_int, C.c_float, _f64p, _f64p, _f64p, C.c_int,
+                                        C.c_int, C.c_float, C.c_int, _i32p]),
     "pcp_seq_collect": (C.c_int, [C.c_void_p, C.c_int, _f32p, C.c_int, _i32p, _i32p, _i32p]),
     "pcp_seq_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "pcp_seq_profile_read": (C.c_int, [C.c_void_p, _f32p, _i32p, C.POINTER(C.c_longlong)]),

@@ -36,14 +36,22 @@ struct SeqDecoded {       // rotated float64 point of frame f; targets also get 
     const float4* const* raw;
     double* const* xyz;
     float4* const* a32;           // a32[f] == nullptr for the last frame (it is nobody's target)
+    const double* place;          // per frame 12 doubles (rotation Q row-major, offset g), or nullptr
     double R[9];
     __device__ void operator()(int f, size_t i, size_t slot) const {
         const float4 p = raw[f][i];
         const double x = (double)p.x, y = (double)p.y, z = (double)p.z;
         // the arithmetic of pcp_frame_decode (one fused chain per row)
-        const double rx = fma(R[2], z, fma(R[1], y, R[0] * x));
-        const double ry = fma(R[5], z, fma(R[4], y, R[3] * x));
-        const double rz = fma(R[8], z, fma(R[7], y, R[6] * x));
+        double rx = fma(R[2], z, fma(R[1], y, R[0] * x));
+        double ry = fma(R[5], z, fma(R[4], y, R[3] * x));
+        double rz = fma(R[8], z, fma(R[7], y, R[6] * x));
+        if (place) {              // (imu_rotation @ cloud.T).T, EnvironmentConstructor.py:169, :209: a second, separately rounded product
+            const double* Q = place + 12 * (size_t)f;
+            const double qx = fma(Q[2], rz, fma(Q[1], ry, Q[0] * rx));
+            const double qy = fma(Q[5], rz, fma(Q[4], ry, Q[3] * rx));
+            const double qz = fma(Q[8], rz, fma(Q[7], ry, Q[6] * rx));
+            rx = qx; ry = qy; rz = qz;
+        }
         double* out = xyz[f];
         out[3 * slot + 0] = rx; out[3 * slot + 1] = ry; out[3 * slot + 2] = rz;
         // ComputeShader.pad_points (:956-961) + the float32 cast of the upload
@@ -173,6 +181,7 @@ struct SeqDescribe {
     LsArgs* ls; FinishArgs* fin; PrepArgs* prep; int* flags;
     int n_pairs, max_scans, pad_lines;
     int last_iter;       // the run's last dispatch: the points it moves are never read (poses come from the steps)
+    const double* place; // per frame 12 doubles (rotation, offset), or nullptr
 };
 
 __global__ void k_seq_describe(const SeqDescribe D) {
@@ -209,6 +218,15 @@ __global__ void k_seq_describe(const SeqDescribe D) {
     D.flags[p] = flag;
     IcpState* st = L.st;
     st->pending = 0; st->iter = 0; st->done = flag ? 1 : 0; st->converged = 0; st->singular = 0;
+    if (D.place && !flag) {
+        // The source is the frame as decoded plus its offset g (the "+ estimated_position" of EnvironmentConstructor.py:209): left as
+        // a pending step (identity, -g) that the first dispatch applies when it reads the frame, x - (-g) == x + g in
+        // float64.  It is no iteration: the loop's own steps are recorded from dispatch 0 on as always.
+        const double* g = D.place + 12 * (size_t)(p + 1) + 9;
+        for (int k = 0; k < 9; ++k) st->R[k] = (k % 4 == 0) ? 1.0 : 0.0;
+        st->t[0] = -g[0]; st->t[1] = -g[1]; st->t[2] = -g[2];
+        st->pending = 1;
+    }
 }
 
 // What the host wants back per pair, gathered into one array so that a single copy fetches a whole run.
@@ -248,6 +266,9 @@ struct pcp_seq {
     float4** raw_dev = nullptr; double** xyz_dev = nullptr; float4** a32_dev = nullptr; unsigned** ends_dev = nullptr;
     int2** scan_dev = nullptr;
     int* n_raw_dev = nullptr; int* n_raw_host[2] = {nullptr, nullptr};     // pinned mirrors, one per result slot
+    // per-frame placements (12 doubles): one device copy per result slot too -- the describe kernel reads it after the
+    // point at which the next submission's uploads may start
+    double* place_dev[2] = {nullptr, nullptr}; double* place_host[2] = {nullptr, nullptr};
     unsigned *n_pts = nullptr, *keep_counts = nullptr, *ring_counts = nullptr;
     int tiles = 0, stride = 0;
     LsArgs* ls_dev = nullptr; FinishArgs* fin_dev = nullptr; PrepArgs* prep_dev = nullptr; int* flags_dev = nullptr;
@@ -273,11 +294,12 @@ int pcp_seq_destroy(pcp_seq* s) {
     for (float4* p : s->raw) if (p) (void)hipFree(p);
     for (double* p : s->xyz) if (p) (void)hipFree(p);
     for (unsigned* p : s->ends) if (p) (void)hipFree(p);
-    void* dev[] = {s->raw_dev, s->xyz_dev, s->a32_dev, s->ends_dev, s->scan_dev, s->n_raw_dev, s->n_pts, s->keep_counts,
+    void* dev[] = {s->raw_dev, s->xyz_dev, s->a32_dev, s->ends_dev, s->scan_dev, s->n_raw_dev, s->place_dev[0], s->place_dev[1], s->n_pts, s->keep_counts,
                    s->ring_counts, s->ls_dev, s->fin_dev, s->prep_dev, s->flags_dev, s->rec_dev};
     for (void* p : dev) if (p) (void)hipFree(p);
     for (int k = 0; k < 2; ++k) {
         if (s->n_raw_host[k]) (void)hipHostFree(s->n_raw_host[k]);
+        if (s->place_host[k]) (void)hipHostFree(s->place_host[k]);
         if (s->rec_host[k]) (void)hipHostFree(s->rec_host[k]);
         if (s->finished[k]) (void)hipEventDestroy(s->finished[k]);
     }
@@ -314,6 +336,7 @@ int pcp_seq_create(int device, int max_frames, int max_points, int max_scans, pc
         e = hipEventCreateWithFlags(&s->finished[k], hipEventDisableTiming);
         if (ok()) e = hipHostMalloc((void**)&s->rec_host[k], (size_t)P * sizeof(SeqRecord));
         if (ok()) e = hipHostMalloc((void**)&s->n_raw_host[k], F * sizeof(int));
+        if (ok()) e = hipHostMalloc((void**)&s->place_host[k], (size_t)F * 12 * sizeof(double));
     }
     auto A = [&](void** p, size_t bytes) { if (ok()) e = hipMalloc(p, bytes); };
     s->raw.assign(F, nullptr); s->xyz.assign(F, nullptr); s->ends.assign(P, nullptr);
@@ -325,6 +348,7 @@ int pcp_seq_create(int device, int max_frames, int max_points, int max_scans, pc
     A((void**)&s->raw_dev, F * sizeof(void*)); A((void**)&s->xyz_dev, F * sizeof(void*));
     A((void**)&s->a32_dev, F * sizeof(void*)); A((void**)&s->ends_dev, P * sizeof(void*)); A((void**)&s->scan_dev, P * sizeof(void*));
     A((void**)&s->n_raw_dev, F * sizeof(int)); A((void**)&s->n_pts, F * sizeof(unsigned));
+    A((void**)&s->place_dev[0], (size_t)F * 12 * sizeof(double)); A((void**)&s->place_dev[1], (size_t)F * 12 * sizeof(double));
     A((void**)&s->keep_counts, (size_t)F * s->stride * sizeof(unsigned));
     A((void**)&s->ring_counts, (size_t)P * s->stride * sizeof(unsigned));
     A((void**)&s->ls_dev, P * sizeof(LsArgs)); A((void**)&s->fin_dev, P * sizeof(FinishArgs));
@@ -376,8 +400,9 @@ int pcp_seq_create(int device, int max_frames, int max_points, int max_scans, pc
     return 0;
 }
 
-int pcp_seq_submit(pcp_seq* s, const float* const* raw_xyzi, const int* n_raw, int n_frames, float min_range,
-                   const double* R9, const double* origin3, int mode, int max_iter, float tol, int full_iter, int* ticket) {
+int pcp_seq_submit_placed(pcp_seq* s, const float* const* raw_xyzi, const int* n_raw, int n_frames, float min_range,
+                          const double* R9, const double* origin3, const double* placements, int mode, int max_iter, float tol,
+                          int full_iter, int* ticket) {
     if (!s) return pcp_fail("null sequence");
     if (!raw_xyzi || !n_raw || !R9 || !origin3 || !ticket) return pcp_fail("null argument");
     if (n_frames < 2 || n_frames > s->max_frames) return pcp_fail("n_frames = %d outside [2, %d]", n_frames, s->max_frames);
@@ -396,6 +421,11 @@ int pcp_seq_submit(pcp_seq* s, const float* const* raw_xyzi, const int* n_raw, i
     if (s->decoded_pending) PCP_CHECK(hipStreamWaitEvent(s->copy, s->decoded, 0));
     memcpy(s->n_raw_host[slot], n_raw, F * sizeof(int));      // this slot's last user has been collected: its copy is done
     PCP_CHECK(hipMemcpyAsync(s->n_raw_dev, s->n_raw_host[slot], F * sizeof(int), hipMemcpyHostToDevice, s->copy));
+    if (placements) {
+        memcpy(s->place_host[slot], placements, (size_t)F * 12 * sizeof(double));
+        PCP_CHECK(hipMemcpyAsync(s->place_dev[slot], s->place_host[slot], (size_t)F * 12 * sizeof(double), hipMemcpyHostToDevice, s->copy));
+    }
+    const double* place = placements ? s->place_dev[slot] : nullptr;
     for (int f = 0; f < F; ++f)
         if (n_raw[f]) PCP_CHECK(hipMemcpyAsync(s->raw[f], raw_xyzi[f], (size_t)n_raw[f] * sizeof(float4), hipMemcpyHostToDevice, s->copy));
     PCP_CHECK(hipEventRecord(s->uploaded, s->copy));
@@ -404,7 +434,7 @@ int pcp_seq_submit(pcp_seq* s, const float* const* raw_xyzi, const int* n_raw, i
     PCP_CHECK(hipStreamWaitEvent(q, s->uploaded, 0));
     const SeqKeepFar keep{(const float4* const*)s->raw_dev, s->n_raw_dev, min_range};
     SeqDecoded dec;
-    dec.raw = (const float4* const*)s->raw_dev; dec.xyz = s->xyz_dev; dec.a32 = s->a32_dev;
+    dec.raw = (const float4* const*)s->raw_dev; dec.xyz = s->xyz_dev; dec.a32 = s->a32_dev; dec.place = place;
     memcpy(dec.R, R9, sizeof(dec.R));
     const dim3 tiles_f(s->tiles, F), tiles_p(s->tiles, P);
     hipLaunchKernelGGL(k_seq_count<SeqKeepFar>, tiles_f, dim3(FR_THREADS), 0, q, keep, s->keep_counts, s->stride);
@@ -424,6 +454,7 @@ int pcp_seq_submit(pcp_seq* s, const float* const* raw_xyzi, const int* n_raw, i
     D.ends = s->ends_dev; D.scan = s->scan_dev; D.ls = s->ls_dev; D.fin = s->fin_dev; D.prep = s->prep_dev; D.flags = s->flags_dev;
     D.n_pairs = P; D.max_scans = s->max_scans; D.pad_lines = (mode == PCP_MODE_PLANE) ? 1 : 0;
     D.last_iter = max_iter - 1;
+    D.place = place;
     hipLaunchKernelGGL(k_seq_describe, dim3(cdiv(P, 64)), dim3(64), 0, q, D);
     PCP_CHECK(hipGetLastError());
     // origin as uploaded: np.resize(origin, (4,)) repeats, [ox, oy, oz, ox] (ComputeShader.py:436-437); it sits in the
@@ -476,6 +507,11 @@ int pcp_seq_submit(pcp_seq* s, const float* const* raw_xyzi, const int* n_raw, i
     *ticket = s->ticket_of[slot];
     s->submitted++;
     return 0;
+}
+
+int pcp_seq_submit(pcp_seq* s, const float* const* raw_xyzi, const int* n_raw, int n_frames, float min_range,
+                   const double* R9, const double* origin3, int mode, int max_iter, float tol, int full_iter, int* ticket) {
+    return pcp_seq_submit_placed(s, raw_xyzi, n_raw, n_frames, min_range, R9, origin3, nullptr, mode, max_iter, tol, full_iter, ticket);
 }
 
 int pcp_seq_collect(pcp_seq* s, int ticket, float* dx_trace, int dx_stride_iters, int* iters, int* converged, int* n_points) {

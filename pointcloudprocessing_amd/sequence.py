@@ -65,9 +65,12 @@ class SequencePipeline:
         self._icp = PointcloudIcpContainer(None)
 
     def submit(self, raw_frames, origin=None, point_to_plane=True, iterations=10, tol=1e-6, full_iter=False,
-               min_range=2.5, rotation=None):
+               min_range=2.5, rotation=None, placements=None):
         """raw_frames: sequence of (N, 4) float32 C-contiguous arrays (rows of a velodyne .bin), e.g. a
-        PinnedFrames or a list of its items; they must not change until collect().  Returns a ticket."""
+        PinnedFrames or a list of its items; they must not change until collect().  Returns a ticket.
+        placements: per frame a (rotation (3, 3), offset (3,)) as imu_placements() makes them, or an (F, 12)
+        array: frame f is turned by its rotation after decoding, and as the source of pair f - 1 it is
+        shifted by its offset before the first iteration (EnvironmentConstructor.py:169, :200-209)."""
         frames = [raw_frames[k] for k in range(len(raw_frames))]
         for a in frames:
             if not (isinstance(a, np.ndarray) and a.dtype == np.float32 and a.ndim == 2 and a.shape[1] == 4
@@ -78,9 +81,17 @@ class SequencePipeline:
         R = np.ascontiguousarray(lidar.aligning_rotation() if rotation is None else rotation, dtype=np.float64)
         o = np.zeros(3) if origin is None else np.ascontiguousarray(origin, dtype=np.float64)
         ticket = C.c_int(-1)
-        check(self._lib.pcp_seq_submit(self._seq, ptrs, i32p(sizes), len(frames), float(min_range), f64p(R), f64p(o),
-                                       MODE_PLANE if point_to_plane else MODE_POINT, int(iterations), float(tol),
-                                       int(bool(full_iter)), C.byref(ticket)))
+        place = None
+        if placements is not None:
+            place = np.ascontiguousarray(
+                [np.concatenate([np.asarray(q, dtype=np.float64).reshape(9), np.asarray(g, dtype=np.float64).reshape(3)])
+                 for q, g in placements] if not isinstance(placements, np.ndarray) else placements, dtype=np.float64)
+            if place.shape != (len(frames), 12):
+                raise ValueError("placements: one (rotation, offset) = 12 numbers per frame")
+        check(self._lib.pcp_seq_submit_placed(self._seq, ptrs, i32p(sizes), len(frames), float(min_range), f64p(R), f64p(o),
+                                              None if place is None else f64p(place),
+                                              MODE_PLANE if point_to_plane else MODE_POINT, int(iterations), float(tol),
+                                              int(bool(full_iter)), C.byref(ticket)))
         self._runs[ticket.value] = (frames, len(frames), int(iterations), bool(point_to_plane), bool(full_iter))
         return ticket.value
 
@@ -160,3 +171,68 @@ def sequence_odometry_raw(raw_frames, point_to_plane=True, iterations=10, rank=0
             pinned.close()
     poses = sharding.gather_poses(local, n_pairs, rank, world, device=gather_device)
     return sharding.compose_odometry(poses)
+
+
+def imu_placements(records):
+    """Per frame (rotation, offset) from its OXTS record, as calculateTransition_imu forms them
+    (EnvironmentConstructor.py:161-165, :200-205 with getCurrentOxtsData :104-105 and getDeltaVelocity :90-95):
+    rotation = getYawRotation(I) @ inv(getTrueRotation(I)) -- the second matrix getCurrentOxtsData returns is inverted
+    and multiplied from the right, whatever the driver's variable names suggest; offset = rotation @ (-velocity *
+    seconds since the previous frame), the dead-reckoned motion since the previous frame (zero for the first)."""
+    out, last = [], None
+    for rec in records:
+        rot = rec.getYawRotation(np.eye(3)) @ np.linalg.inv(rec.getTrueRotation(np.eye(3)))
+        step = np.zeros(3)
+        if last is not None:
+            velocity = -rec.getVelocity()
+            velocity *= (rec.getTime() - last).total_seconds()
+            step = (rot @ velocity.T).T
+        out.append((rot, step))
+        last = rec.getTime()
+    return out
+
+
+def sequence_odometry_imu(raw_frames, records, point_to_plane=True, iterations=10, rank=0, world=1, device=0, chunk=64,
+                          gather_device="cpu", max_points=131072):
+    """Independent frame pairs whose initial guess comes from the IMU alone: frame k, turned by its IMU rotation, is
+    the target of pair k at the origin; frame k + 1, turned by its own and shifted by the IMU's motion estimate, the
+    source.  Pairs are dealt to the ranks in contiguous blocks and run through a SequencePipeline; the per-pair
+    (t_opt, R_opt) are gathered once and chained as the driver chains them (EnvironmentConstructor.py:233-235):
+    position += R_opt @ step - t_opt, rotation = R_opt @ imu_rotation.
+    -> list of (imu_position, refined_position, imu_rotation, refined_rotation) per frame, like prev_poses."""
+    from . import sharding
+    place = imu_placements(records)
+    n_pairs = len(raw_frames) - 1
+    per = -(-n_pairs // world)
+    lo, hi = min(n_pairs, rank * per), min(n_pairs, (rank + 1) * per)
+    local = {}
+    if hi > lo:
+        pinned = PinnedFrames(raw_frames[lo:hi + 1])
+        pipe = SequencePipeline(min(chunk, hi - lo) + 1, max_points=max_points, device=device)
+        try:
+            pending = []
+
+            def take(b0, ticket):
+                for j, pose in enumerate(pipe.poses(pipe.collect(ticket)[0], point_to_plane)):
+                    local[lo + b0 + j] = pose
+
+            for c0 in range(0, hi - lo, chunk):
+                c1 = min(hi - lo, c0 + chunk)
+                pending.append((c0, pipe.submit([pinned[k] for k in range(c0, c1 + 1)], point_to_plane=point_to_plane,
+                                                iterations=iterations, placements=place[lo + c0:lo + c1 + 1])))
+                if len(pending) == 2:
+                    take(*pending.pop(0))
+            for item in pending:
+                take(*item)
+        finally:
+            pipe.close()
+            pinned.close()
+    pairs = sharding.gather_poses(local, n_pairs, rank, world, device=gather_device)
+    imu_pos = refined = np.zeros(3)
+    out = [(imu_pos, refined, place[0][0], place[0][0])]
+    for k, (t_opt, R_opt) in enumerate(pairs):
+        rot, step = place[k + 1]
+        imu_pos = imu_pos + step
+        refined = refined + ((R_opt @ step.T).T - t_opt)
+        out.append((imu_pos, refined, rot, R_opt @ rot))
+    return out

@@ -206,3 +206,56 @@ def test_raw_sequence_odometry_equals_the_float64_driver():
     want = odometry.sequence_odometry([lidar.frame_from_raw(r[:, :3]) for r in raws], iterations=10, batch_size=4)
     for (R, t), (Rw, tw) in zip(got, want):
         assert np.array_equal(R, Rw) and np.array_equal(t, tw)
+
+
+def test_pipeline_with_imu_placements_equals_the_host_driven_pairs():
+    """Independent pairs whose initial guess comes from the IMU alone: frame k turned by its IMU rotation is the
+    target, frame k + 1 turned by its own and shifted by the dead-reckoned step the source -- the arithmetic of
+    calculateTransition_imu (EnvironmentConstructor.py:169, :200-209) in NumPy, registered pair by pair through the
+    device loop, against the same run of raw frames submitted once with placements: steps bit for bit."""
+    from pointcloudprocessing_amd import PinnedFrames, SequencePipeline
+    from pointcloudprocessing_amd.sequence import imu_placements, sequence_odometry_imu
+    imu = golden("ref_imu.npz")
+    ox = reader_from_golden(imu)
+    records = [ox.getOx(k) for k in ox.getfilenames()[:N_FRAMES]]
+    place = imu_placements(records)
+    # the placements are the driver's own numbers: rotation and dead-reckoned path of the reference's pure-IMU run
+    assert np.array_equal(np.stack([q for q, _ in place]), imu["rotation"][:N_FRAMES])
+    assert np.allclose(np.cumsum([g for _, g in place], axis=0), imu["imu_pos"][:N_FRAMES], atol=1e-12)
+    raws = [_raw4(r) for r in kitti_sequence_raw()]
+    frames = [lidar.frame_from_raw(r[:, :3]) for r in raws]
+    pinned = PinnedFrames(raws)
+    pipe = SequencePipeline(max_frames=N_FRAMES, max_points=131072)
+    cs = ComputeShader(maxPointsPerCloud=131072, maxScans=100)
+    icp = PointcloudIcpContainer(cs)
+    try:
+        steps, n_pts = pipe.collect(pipe.submit(pinned, point_to_plane=True, iterations=10, placements=place))
+        plain, _ = pipe.collect(pipe.submit(pinned, point_to_plane=True, iterations=10))
+        poses = pipe.poses(steps, True)
+        first_steps, first_plain = [], []
+        for p in range(N_FRAMES - 1):
+            target = (place[p][0] @ frames[p].T).T
+            source = (place[p + 1][0] @ frames[p + 1].T).T + place[p + 1][1]
+            icp.preparePointToPlane(target, np.zeros(3), source)
+            dx, conv, _, _ = cs.icpRun(source, MODE_PLANE, 10, tol=1e-6, full_iter=False, want_hb=False)
+            assert conv == steps[p][1] and np.array_equal(bits(dx), bits(steps[p][0])), p
+            t_opt, R_opt = icp.full_pt2pl(target, source, np.zeros(3), iterations=10)
+            assert np.array_equal(t_opt, poses[p][0]) and np.array_equal(R_opt, poses[p][1])
+            first_steps.append(np.linalg.norm(steps[p][0][0][:3]))
+            first_plain.append(np.linalg.norm(plain[p][0][0][:3]))
+        # the guess does its work: the first iteration has centimetres left to correct instead of decimetres
+        assert np.median(first_steps) < 0.25 * np.median(first_plain), (first_steps, first_plain)
+        # the chained trajectory stays within decimetres of the dead-reckoned one and moves a third of a metre per sweep
+        track = sequence_odometry_imu(raws, records, point_to_plane=True, iterations=10, chunk=5)
+        refined = np.stack([t[1] for t in track])
+        assert np.array_equal(np.stack([t[2] for t in track]), imu["rotation"][:N_FRAMES])
+        assert np.allclose(np.stack([t[0] for t in track]), imu["imu_pos"][:N_FRAMES], atol=1e-12)
+        assert np.linalg.norm(refined - imu["imu_pos"][:N_FRAMES], axis=1).max() < 0.5
+        hops = np.linalg.norm(np.diff(refined, axis=0), axis=1)
+        assert np.all((hops > 0.25) & (hops < 0.45)), hops
+        for k in range(N_FRAMES - 1):           # chunked submissions (5 pairs at a time) give the same pairs
+            assert np.array_equal(track[k + 1][3], poses[k][1] @ place[k + 1][0])
+    finally:
+        cs.cleanup()
+        pipe.close()
+        pinned.close()
