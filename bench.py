@@ -362,7 +362,7 @@ def extras(raws, device):
     cs.cleanup()
 
     # --- configs[2]: 1 M synthetic points, voxel sizes 0.1 ... 2 m: voxelize + Morton sort + NN scan
-    sweeps = [lidar.synthetic_scan(s, rings=64, steps=1953) + np.array([0.5 * s, 0.0, 0.0]) for s in range(8)]
+    sweeps = [lidar.synthetic_scan(s, rings=64, steps=1953) + np.array([0.5 * s, 0.0, 0.0]) for s in range(10)]
     cloud = np.concatenate(sweeps)
     rng = np.random.default_rng(1)
     q = cloud + rng.normal(0, 0.05, cloud.shape)
@@ -394,17 +394,17 @@ def extras(raws, device):
                      "grid_build_ms": float(info["build_ms"]), "nn_ms": float(qms), "nn_queries_per_s": len(q) / (qms * 1e-3)})
     grid.cleanup()
     cs.cleanup()
-    out["voxel_sweep"] = {"what": "configs[2]: %d synthetic LiDAR-like points (8 sweeps): Voxelizer.addPoints per sweep, Morton radix "
+    out["voxel_sweep"] = {"what": "configs[2]: %d synthetic LiDAR-like points (10 sweeps): Voxelizer.addPoints per sweep, Morton radix "
                                   "sort + cell table of the whole cloud, exact NN of the cloud jittered by 5 cm" % len(cloud),
                           "rows": rows}
     return out
 
 
-def scan_to_map_leg(raws, rank, world, device, dist, backend):
+def scan_to_map_leg(raws, rank, world, device, dist, exchange):
     """configs[4] at N > 1: a scan registered against an accumulated map that is split over the ranks by key range
     (100 sweeps = 12.3 M points per rank), the 8x8 tile summed by an RCCL all-reduce per iteration through the
-    library's own communicator (pcp_comm_*, pcp_grid_icp_run_comm).  Over gloo (rehearsal) the tile goes through
-    torch.distributed instead."""
+    library's own communicator (pcp_comm_*, pcp_grid_icp_run_comm).  With exchange "gloo" (rehearsal: ranks sharing
+    a card) the tile goes through torch.distributed instead."""
     import torch
     from pointcloudprocessing_amd.scan_to_map import MODE_POINT, MapRegistration, RcclComm
     a, b = lidar.frame_from_raw(raws[0][:, :3]), lidar.frame_from_raw(raws[1][:, :3])
@@ -413,7 +413,7 @@ def scan_to_map_leg(raws, rank, world, device, dist, backend):
     map_pts = np.concatenate([a + k * step for k in range(sweeps)])
     k = sweeps // 2
     scan = b + (k + 1) * step + np.array([0.04, 0.0, 0.05])
-    comm = RcclComm(rank, world, device) if backend == "nccl" else None
+    comm = RcclComm(rank, world, device) if exchange == "rccl" else None
     c0 = time.perf_counter()
     reg = MapRegistration(map_pts, 0.5, nn_cell=0.15, rank=rank, world=world, device=device, comm=comm)
     build_s = time.perf_counter() - c0
@@ -441,19 +441,49 @@ def scan_to_map_leg(raws, rank, world, device, dist, backend):
             "translation": [float(v) for v in res[0]]}
 
 
-def guarded(fn, seconds, on_timeout):
-    """Runs fn(); if it has not returned after `seconds` (a collective that never completes cannot be interrupted),
-    on_timeout() runs on a timer thread and the process ends there."""
-    import threading
-    timer = threading.Timer(seconds, on_timeout)
-    timer.daemon = True
-    timer.start()
+def scan_to_map_child():
+    """`bench.py --leg scan-to-map`: one rank of the leg above in a process of its own (control traffic over gloo on
+    the port the parent chose).  The collective has never run on more than one GPU where this was written, so the
+    parent keeps it at arm's length: a crash or a hang here costs the bench line one object, not the line."""
+    import torch
+    import torch.distributed as dist
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    device = int(os.environ.get("LOCAL_RANK", "0")) % max(1, torch.cuda.device_count())
+    torch.cuda.set_device(device)
+    dist.init_process_group("gloo")
+    raws, _ = real_frames()
+    out = scan_to_map_leg(raws, rank, world, device, dist, os.environ.get("PCP_LEG_EXCHANGE", "rccl"))
+    dist.barrier()
+    if rank == 0:
+        print("PCP_LEG " + json.dumps(out), flush=True)
+    dist.destroy_process_group()
+
+
+def run_leg_in_children(rank, dist, exchange, seconds):
+    """Every rank starts its child; rank 0 picks the rendezvous port and returns what its child printed."""
+    import socket
+    import subprocess
+    box = [None]
+    if rank == 0:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            box[0] = sk.getsockname()[1]
+    dist.broadcast_object_list(box, src=0)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(box[0]), PCP_LEG_EXCHANGE=exchange)
+    for name in ("TORCHELASTIC_RUN_ID", "TORCHELASTIC_USE_AGENT_STORE", "GROUP_RANK", "ROLE_RANK"):
+        env.pop(name, None)       # the child makes its own store on the new port
     try:
-        return fn()
-    except Exception as e:          # the headline must survive a failure of an extra leg
-        return {"error": "%s: %s" % (type(e).__name__, e)}
-    finally:
-        timer.cancel()
+        done = subprocess.run([sys.executable, os.path.abspath(__file__), "--leg", "scan-to-map"], env=env, capture_output=True,
+                              text=True, timeout=seconds)
+    except subprocess.TimeoutExpired:
+        return {"error": "did not finish within %d s (child ended)" % seconds}
+    for line in done.stdout.splitlines()[::-1]:
+        if line.startswith("PCP_LEG "):
+            return json.loads(line[8:])
+    if rank != 0 and done.returncode == 0:
+        return None
+    tail = (done.stderr or "").strip().splitlines()[-3:]
+    return {"error": "child exit code %d: %s" % (done.returncode, " | ".join(tail)[-400:])}
 
 
 def main():
@@ -466,9 +496,12 @@ def main():
     ap.add_argument("--workload", choices=("sequence", "moved-copy"), default="sequence")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
+    ap.add_argument("--leg", choices=("scan-to-map",), default=None, help=argparse.SUPPRESS)
     ap.add_argument("--no-latency", action="store_true",
                     help="skip the single-pair latency legs (profiling passes: every launch of the fused kernel then is a full step's)")
     args = ap.parse_args()
+    if args.leg == "scan-to-map":
+        return scan_to_map_child()
 
     import torch
     rank = int(os.environ.get("RANK", "0"))
@@ -571,12 +604,9 @@ def main():
     else:
         out = None
     if dist is not None and not args.no_extras:
-        def give_up():
-            if out is not None:
-                out["scan_to_map"] = {"error": "did not finish within its time budget"}
-                print(json.dumps(out), flush=True)
-            os._exit(0)
-        leg = guarded(lambda: scan_to_map_leg(raws, rank, world, device, dist, backend), 240.0, give_up)
+        torch.cuda.synchronize()
+        leg = run_leg_in_children(rank, dist, os.environ.get("PCP_BENCH_LEG_EXCHANGE", "rccl" if backend == "nccl" else "gloo"),
+                                  int(os.environ.get("PCP_BENCH_LEG_SECONDS", "240")))
         if out is not None:
             out["scan_to_map"] = leg
     if out is not None:
