@@ -259,3 +259,50 @@ def test_pipeline_with_imu_placements_equals_the_host_driven_pairs():
         cs.cleanup()
         pipe.close()
         pinned.close()
+
+
+def _synthetic_raw(seed, rings, steps, n_exact=None):
+    """A raw record (sensor axes, float32 rows x, y, z, 0) of a synthetic sweep; n_exact pads or cuts it to a given
+    number of raw rows (padding repeats the last ring's points, which keeps the ring order)."""
+    back = lidar.aligning_rotation().T
+    cloud = lidar.synthetic_scan(seed, rings=rings, steps=steps, pose_t=np.array([0.2 * seed, 0.0, 0.0]))
+    raw = (back @ cloud.T).T.astype(np.float32)
+    if n_exact is not None:
+        while len(raw) < n_exact:
+            raw = np.concatenate([raw, raw[-min(len(raw), n_exact - len(raw)):]])
+        raw = raw[:n_exact]
+    return _raw4(raw)
+
+
+@pytest.mark.parametrize("plane", [True, False])
+def test_pipeline_on_ragged_frames_equals_the_pair_by_pair_path(plane):
+    """Frames of very different sizes and ring counts in one submission -- a full-capacity frame, one that ends on a
+    compaction tile boundary, one of three short rings, one a tile plus one point long: every pair equals the
+    pair-by-pair device path bit for bit; identity placements change nothing."""
+    from pointcloudprocessing_amd import PinnedFrames, SequencePipeline
+    from pointcloudprocessing_amd.frame import DeviceFrame, register_frames
+    cap = 16384
+    raws = [_synthetic_raw(0, 32, 400), _synthetic_raw(1, 64, 300, n_exact=cap), _synthetic_raw(2, 3, 60),
+            _synthetic_raw(3, 16, 128, n_exact=2048), _synthetic_raw(4, 64, 40), _synthetic_raw(5, 8, 300, n_exact=2049),
+            _synthetic_raw(6, 40, 333)]
+    pinned = PinnedFrames(raws)
+    pipe = SequencePipeline(max_frames=len(raws), max_points=cap)
+    cs = ComputeShader(maxPointsPerCloud=cap, maxScans=100)
+    fa, fb = DeviceFrame(cap), DeviceFrame(cap)
+    try:
+        steps, n_pts = pipe.collect(pipe.submit(pinned, point_to_plane=plane, iterations=4))
+        ident = [(np.eye(3), np.zeros(3))] * len(raws)
+        same, n_same = pipe.collect(pipe.submit(pinned, point_to_plane=plane, iterations=4, placements=ident))
+        assert np.array_equal(n_pts, n_same)
+        for p in range(len(raws) - 1):
+            assert fa.decode(raws[p]) == n_pts[p] and fb.decode(raws[p + 1]) == n_pts[p + 1]
+            _, dx, conv = register_frames(cs, fa, fb, np.zeros(3), point_to_plane=plane, iterations=4)
+            assert conv == steps[p][1] and np.array_equal(bits(dx), bits(steps[p][0])), p
+            assert np.array_equal(bits(steps[p][0]), bits(same[p][0])), p
+        assert len({int(n) for n in n_pts}) == len(raws)          # really ragged
+    finally:
+        fa.cleanup()
+        fb.cleanup()
+        cs.cleanup()
+        pipe.close()
+        pinned.close()
