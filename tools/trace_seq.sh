@@ -1,13 +1,13 @@
 # Kernel trace of the bench's sequence workload: per-kernel stats and the per-dispatch durations of the
 # search kernels in launch order (iteration 0 of every step searches all rings).
-#   tools/trace_seq.sh <tag>
+#   tools/trace_seq.sh <tag> [workload]
 set -e
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/trace_$1
 mkdir -p $O
 cd /tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/kt -o kt -- python3 $R/bench.py --no-cpu-baseline --no-extras --no-latency --steps 3 --warmup 1 > $O/kt.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/kt -o kt -- python3 $R/bench.py --workload ${2:-sequence} --no-cpu-baseline --no-extras --no-latency --steps 3 --warmup 1 > $O/kt.log 2>&1
 cd $R
 python tools/rocpd_export.py stats $O/kt/kt_results.db $O/kernel_stats.csv
 python tools/kstats.py $O/kernel_stats.csv > $O/kstats.txt
