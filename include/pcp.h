@@ -208,6 +208,17 @@ int pcp_voxel_counts_read(pcp_ctx* ctx, int first_row, int n_rows, int32_t* coun
 int pcp_voxel_stage(pcp_ctx* ctx, float* voxel_stat, int stat_rows, int stored, int max_points,
                     int filter_outliers, int stage_everything, int max_staging,
                     int32_t* counter16, int32_t* stage_out);
+/* A device copy of the Voxelizer's global point store (added_points, filled by handleAddingPoints,
+ * Voxelizer.py:398-425): while switched on, every pcp_voxelize* call also keeps its points at
+ * [begin_index, begin_index + n) of a device array (16 bytes per point, doubling).  Switch it on before a map's
+ * first dispatch; pcp_voxel_reset empties it, switching it off frees it. */
+int pcp_voxel_store_enable(pcp_ctx* ctx, int on);
+/* The points of the rows the last pcp_voxel_stage call staged, looked up in that store on the device: what the
+ * reference gathers on the host per staged row before it hands the voxel on (Voxelizer.py:130-133 with
+ * getStoredPointsFromVoxelDataSlice :396-399: ids = row[1 : min(row[0] + 1, max_points)]), row after row in
+ * staging order as n_points x 3 float64 in device memory.  The buffer belongs to the context and is valid until
+ * the next call of this function; the call returns when it is complete.  n_rows (or NULL) receives the rows staged. */
+int pcp_voxel_staged_points(pcp_ctx* ctx, const double** xyz_dev, size_t* n_points, int* n_rows);
 
 /* ---- batches of independent frame pairs -----------------------------------
  * Consecutive frame pairs of a sequence are independent registrations
@@ -292,6 +303,12 @@ int pcp_grid_build_slab(pcp_grid* grid, const double* xyz, size_t n, double cell
 int pcp_grid_append(pcp_grid* grid, const double* xyz, size_t n, const float* normals_xyzw, long long first_id);
 int pcp_grid_append_slab(pcp_grid* grid, const double* xyz, size_t n, const float* normals_xyzw, double own_cell,
                          unsigned long long lo, unsigned long long hi, long long first_id, size_t* n_kept);
+/* pcp_grid_append / pcp_grid_append_slab for points already in device memory (n x 3 float64 on the grid's device,
+ * e.g. what pcp_voxel_staged_points returns); no normals.  The work that produced the buffer must have completed
+ * (the grid runs on a stream of its own); the buffer is read only and may be reused when the call returns. */
+int pcp_grid_append_dev(pcp_grid* grid, const double* xyz_dev, size_t n, long long first_id);
+int pcp_grid_append_slab_dev(pcp_grid* grid, const double* xyz_dev, size_t n, double own_cell, unsigned long long lo,
+                             unsigned long long hi, long long first_id, size_t* n_kept);
 /* Facts about the last build: points, occupied cells, extent in cells, radix
  * passes, device time of the whole build and of the sort alone (ms). Any pointer may be NULL. */
 int pcp_grid_info(pcp_grid* grid, unsigned long long* n_points, unsigned long long* n_cells, int* extent3,

@@ -61,6 +61,8 @@ SIGNATURES = {
     "pcp_voxelize_xyz": (C.c_int, [_ctx, _f32p, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, _i32p, C.c_int, _f32p]),
     "pcp_voxelize_rows": (C.c_int, [_ctx, _f32p, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, _i32p, C.c_int, _f32p]),
     "pcp_voxel_stage": (C.c_int, [_ctx, _f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _i32p, _i32p]),
+    "pcp_voxel_store_enable": (C.c_int, [_ctx, C.c_int]),
+    "pcp_voxel_staged_points": (C.c_int, [_ctx, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), _i32p]),
     "pcp_grid_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
     "pcp_grid_destroy": (C.c_int, [C.c_void_p]),
     "pcp_grid_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
@@ -69,6 +71,9 @@ SIGNATURES = {
     "pcp_grid_append": (C.c_int, [C.c_void_p, _f64p, C.c_size_t, _f32p, C.c_longlong]),
     "pcp_grid_append_slab": (C.c_int, [C.c_void_p, _f64p, C.c_size_t, _f32p, C.c_double, C.c_ulonglong, C.c_ulonglong, C.c_longlong,
                                        C.POINTER(C.c_size_t)]),
+    "pcp_grid_append_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_longlong]),
+    "pcp_grid_append_slab_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_double, C.c_ulonglong, C.c_ulonglong,
+                                           C.c_longlong, C.POINTER(C.c_size_t)]),
     "pcp_grid_partition": (C.c_int, [C.c_int, _f64p, C.c_size_t, C.c_double, C.c_int, C.POINTER(C.c_ulonglong)]),
     "pcp_grid_build_slab": (C.c_int, [C.c_void_p, _f64p, C.c_size_t, C.c_double, _f32p, C.c_double, C.c_ulonglong, C.c_ulonglong, C.POINTER(C.c_size_t)]),
     "pcp_grid_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong), _i32p, _i32p, _f32p, _f32p]),

@@ -87,6 +87,26 @@ class CellGrid:
         self.data = None                                    # the host copy of the first build no longer is the map
         return kept
 
+    def append_device(self, xyz_dev, n, first_id=None, slab=None):
+        """append() for n points that already lie in this device's memory as n x 3 float64 (xyz_dev: address, e.g.
+        from ComputeShader.stagedPointsDevice); whatever produced them must have completed."""
+        n = int(n)
+        first = self.n if first_id is None else int(first_id)
+        if n == 0:
+            return 0
+        if slab is None:
+            check(self._lib.pcp_grid_append_dev(self._g, C.c_void_p(int(xyz_dev)), n, first))
+            kept = n
+        else:
+            k = C.c_size_t(0)
+            check(self._lib.pcp_grid_append_slab_dev(self._g, C.c_void_p(int(xyz_dev)), n, float(slab[0]), int(slab[1]),
+                                                     int(slab[2]), first, C.byref(k)))
+            kept = int(k.value)
+        self.n = max(self.n, first + n)
+        self.held += kept
+        self.data = None
+        return kept
+
     def info(self):
         n, cells = C.c_ulonglong(0), C.c_ulonglong(0)
         ext = np.zeros(3, dtype=np.int32)

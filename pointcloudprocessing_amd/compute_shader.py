@@ -340,6 +340,18 @@ class ComputeShader:
             return voxel_statistics, self.voxel_stage_out[:staged]
         return voxel_statistics, []
 
+    def keepPointStore(self, on=True):
+        """Keep a device copy of the Voxelizer's global point store (every dispatched cloud at its begin_index), so
+        that staged voxels can be resolved to points without the host (stagedPointsDevice)."""
+        check(self._lib.pcp_voxel_store_enable(self._ctx, int(bool(on))))
+
+    def stagedPointsDevice(self):
+        """(device address of n x 3 float64, n, rows): the points of the rows the last prepareDispatchVoxelStager call
+        staged, row after row, gathered on the device; valid until the next call."""
+        ptr, n, rows = C.c_void_p(), C.c_size_t(0), np.zeros(1, dtype=np.int32)
+        check(self._lib.pcp_voxel_staged_points(self._ctx, C.byref(ptr), C.byref(n), i32p(rows)))
+        return (ptr.value or 0), int(n.value), int(rows[0])
+
     def getFullVoxelData(self, prev_stored_voxels, max_points, voxelizer_voxel_data):
         """:946-954 -- fills voxelizer_voxel_data[:prev_stored_voxels] in place."""
         out = voxelizer_voxel_data

@@ -1582,7 +1582,8 @@ int pcp_grid_build_slab(pcp_grid* g, const double* xyz, size_t n, double cell, c
 }
 
 static int append_host(pcp_grid* g, const double* xyz, size_t n, const float* normals_xyzw, long long first_id,
-                       bool slab, double own_cell, unsigned long long lo, unsigned long long hi, size_t* n_kept) {
+                       bool slab, double own_cell, unsigned long long lo, unsigned long long hi, size_t* n_kept,
+                       bool xyz_on_device = false) {
     if (!g) return pcp_fail("null grid");
     if (!(g->cell > 0.0)) return pcp_fail("the grid has no cell size yet: call pcp_grid_build first (an empty map will do)");
     if (n && !xyz) return pcp_fail("xyz is null");
@@ -1598,11 +1599,17 @@ static int append_host(pcp_grid* g, const double* xyz, size_t n, const float* no
     unsigned *d_ids = nullptr, *d_counts = nullptr;
     int* d_bad = nullptr;
     auto cleanup = [&]() {
-        for (void* q : {(void*)d_xyz, (void*)d_keep, (void*)d_nrm, (void*)d_nkeep, (void*)d_ids, (void*)d_counts, (void*)d_bad})
+        for (void* q : {(void*)(xyz_on_device ? nullptr : d_xyz), (void*)d_keep, (void*)d_nrm, (void*)d_nkeep, (void*)d_ids,
+                        (void*)d_counts, (void*)d_bad})
             if (q) (void)hipFree(q);
     };
-    hipError_t e = hipMalloc(&d_xyz, n * 24);
-    if (e == hipSuccess) e = hipMemcpyAsync(d_xyz, xyz, n * 24, hipMemcpyHostToDevice, s);
+    hipError_t e = hipSuccess;
+    if (xyz_on_device) {
+        d_xyz = const_cast<double*>(xyz);            // read only; the caller's work on it has completed (see pcp.h)
+    } else {
+        e = hipMalloc(&d_xyz, n * 24);
+        if (e == hipSuccess) e = hipMemcpyAsync(d_xyz, xyz, n * 24, hipMemcpyHostToDevice, s);
+    }
     if (e == hipSuccess && normals_xyzw) {
         e = hipMalloc(&d_nrm, n * 16);
         if (e == hipSuccess) e = hipMemcpyAsync(d_nrm, normals_xyzw, n * 16, hipMemcpyHostToDevice, s);
@@ -1648,6 +1655,17 @@ int pcp_grid_append_slab(pcp_grid* g, const double* xyz, size_t n, const float* 
     if (!(own_cell > 0.0)) return pcp_fail("partition cell size must be positive");
     if (lo > hi) return pcp_fail("owned key range is empty");
     return append_host(g, xyz, n, normals_xyzw, first_id, true, own_cell, lo, hi, n_kept);
+}
+
+int pcp_grid_append_dev(pcp_grid* g, const double* xyz_dev, size_t n, long long first_id) {
+    return append_host(g, xyz_dev, n, nullptr, first_id, false, 1.0, 0, 0, nullptr, true);
+}
+
+int pcp_grid_append_slab_dev(pcp_grid* g, const double* xyz_dev, size_t n, double own_cell, unsigned long long lo,
+                             unsigned long long hi, long long first_id, size_t* n_kept) {
+    if (!(own_cell > 0.0)) return pcp_fail("partition cell size must be positive");
+    if (lo > hi) return pcp_fail("owned key range is empty");
+    return append_host(g, xyz_dev, n, nullptr, first_id, true, own_cell, lo, hi, n_kept, true);
 }
 
 int pcp_grid_partition(int device, const double* xyz, size_t n, double own_cell, int world, unsigned long long* cuts) {

@@ -37,12 +37,20 @@ struct pcp_voxel_state {
              *counts = nullptr;
     int ins_cap = 0;
     int* mm = nullptr;       // 8 ints: coordinate range of the unknown points
+    // device copy of the Voxelizer's global point store (added_points, Voxelizer.py:398-425), kept on request:
+    // point id = begin_index + i of the dispatch that brought it
+    bool keep_store = false;
+    float4* store = nullptr; size_t store_cap = 0, store_n = 0;
+    int last_staged = 0;     // rows the last pcp_voxel_stage call staged
+    unsigned* staged_off = nullptr;          // stage_rows + 2: exclusive scan of the staged rows' point counts, total, error flag
+    double* staged_xyz = nullptr; size_t staged_cap = 0;
 };
 
 void pcp_voxel_state_free(pcp_voxel_state* v) {
     if (!v) return;
     void* bufs[] = {v->table, v->data, v->stat, v->stat_in, v->stage, v->unknown, v->pts, v->debug, v->counter,
-                    v->table2, v->flag, v->k0, v->k1, v->v0, v->v1, v->heads, v->hist, v->totals, v->base, v->counts, v->mm};
+                    v->table2, v->flag, v->k0, v->k1, v->v0, v->v1, v->heads, v->hist, v->totals, v->base, v->counts, v->mm,
+                    v->store, v->staged_off, v->staged_xyz};
     for (void* p : bufs)
         if (p) (void)hipFree(p);
     delete v;
@@ -359,6 +367,58 @@ __global__ void k_gather_counts(const int* __restrict__ data, int first_row, int
     if (k < n_rows) out[k] = data[(size_t)(first_row + k) * max_points];
 }
 
+// Points of the staged rows, row after row in staging order, each row's ids in row order: what
+// Voxelizer.getStoredPointsFromVoxelDataSlice (:396-399) looks up per row, ids = row[1 : min(row[0] + 1, width)].
+// One block: exclusive scan of the rows' point counts (rows <= 1024 per pass, carried over passes).
+__global__ void __launch_bounds__(1024) k_staged_offsets(const int* __restrict__ stage, int rows, int width,
+                                                          unsigned* __restrict__ off) {
+    __shared__ unsigned sc[1024];
+    __shared__ unsigned run;
+    if (threadIdx.x == 0) run = 0;
+    __syncthreads();
+    for (int base = 0; base < rows; base += 1024) {
+        const int r = base + threadIdx.x;
+        unsigned n = 0;
+        if (r < rows) {
+            const int cnt = stage[(size_t)r * width];
+            n = (unsigned)max(0, min(cnt, width - 1));
+        }
+        sc[threadIdx.x] = n;
+        __syncthreads();
+        for (int d = 1; d < 1024; d <<= 1) {
+            const unsigned t = threadIdx.x >= (unsigned)d ? sc[threadIdx.x - d] : 0u;
+            __syncthreads();
+            sc[threadIdx.x] += t;
+            __syncthreads();
+        }
+        if (r < rows) off[r] = run + sc[threadIdx.x] - n;
+        __syncthreads();
+        if (threadIdx.x == 0) run += sc[1023];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { off[rows] = run; off[rows + 1] = 0; }
+}
+
+__global__ void __launch_bounds__(256) k_staged_gather(const int* __restrict__ stage, int width, const float4* __restrict__ store,
+                                                        size_t store_n, unsigned* __restrict__ off, int rows,
+                                                        double* __restrict__ out) {
+    const int r = blockIdx.x;
+    const unsigned first = off[r], n = off[r + 1] - first;        // off[rows] is the total: the last row's end
+    const int* ids = stage + (size_t)r * width + 1;
+    for (unsigned j = threadIdx.x; j < n; j += blockDim.x) {
+        const int id = ids[j];
+        double x = 0.0, y = 0.0, z = 0.0;
+        if (id < 0 || (size_t)id >= store_n) {
+            off[rows + 1] = 1;                                     // an id the store does not hold
+        } else {
+            const float4 p = store[id];
+            x = (double)p.x; y = (double)p.y; z = (double)p.z;
+        }
+        double* o = out + 3 * (size_t)(first + j);
+        o[0] = x; o[1] = y; o[2] = z;
+    }
+}
+
 int use(pcp_ctx* c) {
     if (!c) return pcp_fail("null context");
     PCP_CHECK(hipSetDevice(c->device));
@@ -497,6 +557,26 @@ static int voxelize_impl(pcp_ctx* c, const float* pts_xyzw, int floats_per_point
         else hipLaunchKernelGGL(k_pad_rows, dim3(cdiv(n, 256)), dim3(256), 0, c->stream, staging, n, v->pts);
         PCP_CHECK(hipGetLastError());
     }
+    if (v->keep_store) {
+        if (begin_index < 0) return pcp_fail("begin_index must not be negative");
+        const size_t end = (size_t)begin_index + (size_t)n;
+        if (end > v->store_cap) {                 // doubling, like the host store (Voxelizer.py:402-416)
+            size_t cap = v->store_cap ? v->store_cap : (size_t)1 << 20;
+            while (cap < end) cap *= 2;
+            float4* bigger = nullptr;
+            PCP_CHECK(hipMalloc(&bigger, cap * sizeof(float4)));
+            hipError_t e = hipMemsetAsync(bigger, 0, cap * sizeof(float4), c->stream);
+            if (e == hipSuccess && v->store_n)
+                e = hipMemcpyAsync(bigger, v->store, v->store_n * sizeof(float4), hipMemcpyDeviceToDevice, c->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+            if (e != hipSuccess) { (void)hipFree(bigger); return pcp_fail("growing the point store: %s", hipGetErrorString(e)); }
+            if (v->store) (void)hipFree(v->store);
+            v->store = bigger;
+            v->store_cap = cap;
+        }
+        PCP_CHECK(hipMemcpyAsync(v->store + begin_index, v->pts, (size_t)n * sizeof(float4), hipMemcpyDeviceToDevice, c->stream));
+        if (end > v->store_n) v->store_n = end;
+    }
     hipLaunchKernelGGL(k_voxelize, dim3(cdiv(n, 256)), dim3(256), 0, c->stream, v->pts, n, v->table, stored, v->data,
                        v->data_rows, max_points, begin_index, voxel_size, v->unknown, debug ? v->debug : nullptr);
     PCP_CHECK(hipGetLastError());
@@ -518,9 +598,12 @@ int pcp_voxel_reset(pcp_ctx* c) {
     PCP_CHECK(hipStreamSynchronize(c->stream));
     if (v->table) PCP_CHECK(hipFree(v->table));
     if (v->data) PCP_CHECK(hipFree(v->data));
+    if (v->store) PCP_CHECK(hipFree(v->store));
+    v->store = nullptr; v->store_cap = v->store_n = 0; v->last_staged = 0;
     v->table = nullptr; v->table_rows = v->table_valid = 0;
     v->data = nullptr;  v->data_rows = v->data_width = 0;
     v->last_unknown = -1;
+    v->last_n = 0;
     return 0;
 }
 
@@ -715,11 +798,64 @@ int pcp_voxel_stage(pcp_ctx* c, float* voxel_stat, int stat_rows, int stored, in
     PCP_CHECK(hipStreamSynchronize(c->stream));
     for (int i = 0; i < 16; ++i) counter16[i] = host_counter[i];
     const int staged = host_counter[0];
+    v->last_staged = 0;
     if (staged < 0 || staged > max_staging) return pcp_fail("corrupt staging counter %d", staged);
+    v->last_staged = staged;
     if (stage_out && staged > 0) {
         PCP_CHECK(hipMemcpyAsync(stage_out, v->stage, (size_t)staged * max_points * sizeof(int), hipMemcpyDeviceToHost, c->stream));
         PCP_CHECK(hipStreamSynchronize(c->stream));
     }
+    return 0;
+}
+
+int pcp_voxel_store_enable(pcp_ctx* c, int on) {
+    if (int e = use(c)) return e;
+    pcp_voxel_state* v = c->vox;
+    if (on && !v->keep_store && v->last_n > 0 && v->store_n == 0)
+        return pcp_fail("the point store must be switched on before the first dispatch of a map (ids count from there)");
+    v->keep_store = on != 0;
+    if (!on) {
+        PCP_CHECK(hipStreamSynchronize(c->stream));
+        if (v->store) PCP_CHECK(hipFree(v->store));
+        v->store = nullptr; v->store_cap = v->store_n = 0;
+    }
+    return 0;
+}
+
+int pcp_voxel_staged_points(pcp_ctx* c, const double** xyz_dev, size_t* n_points, int* n_rows) {
+    if (int e = use(c)) return e;
+    pcp_voxel_state* v = c->vox;
+    if (!xyz_dev || !n_points) return pcp_fail("null output");
+    *xyz_dev = nullptr; *n_points = 0;
+    if (n_rows) *n_rows = v->last_staged;
+    if (!v->keep_store) return pcp_fail("the device point store is off (pcp_voxel_store_enable)");
+    const int rows = v->last_staged;
+    if (rows == 0) return 0;
+    if (!v->stage || rows > v->stage_rows) return pcp_fail("no staging buffer for %d rows", rows);
+    if (!v->staged_off) PCP_CHECK(hipMalloc(&v->staged_off, ((size_t)v->stage_rows + 2) * sizeof(unsigned)));
+    hipLaunchKernelGGL(k_staged_offsets, dim3(1), dim3(1024), 0, c->stream, v->stage, rows, v->stage_width, v->staged_off);
+    PCP_CHECK(hipGetLastError());
+    unsigned total = 0;
+    PCP_CHECK(hipMemcpyAsync(&total, v->staged_off + rows, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+    PCP_CHECK(hipStreamSynchronize(c->stream));
+    if (total == 0) return 0;
+    if ((size_t)total > v->staged_cap) {
+        if (v->staged_xyz) PCP_CHECK(hipFree(v->staged_xyz));
+        v->staged_xyz = nullptr; v->staged_cap = 0;
+        size_t cap = (size_t)1 << 16;
+        while (cap < total) cap *= 2;
+        PCP_CHECK(hipMalloc(&v->staged_xyz, cap * 3 * sizeof(double)));
+        v->staged_cap = cap;
+    }
+    hipLaunchKernelGGL(k_staged_gather, dim3(rows), dim3(256), 0, c->stream, v->stage, v->stage_width, v->store, v->store_n,
+                       v->staged_off, rows, v->staged_xyz);
+    PCP_CHECK(hipGetLastError());
+    unsigned bad = 0;
+    PCP_CHECK(hipMemcpyAsync(&bad, v->staged_off + rows + 1, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+    PCP_CHECK(hipStreamSynchronize(c->stream));
+    if (bad) return pcp_fail("a staged row names a point the device store does not hold (%zu points stored)", v->store_n);
+    *xyz_dev = v->staged_xyz;
+    *n_points = total;
     return 0;
 }
 

@@ -12,12 +12,31 @@ import numpy as np
 class MapSink:
     needs_renderer = False            # Voxelizer._hand_off feeds it without a renderer
 
-    def __init__(self, target):
-        """target: a CellGrid (append) or a scan_to_map.MapRegistration (ingest: routed by key range)."""
+    def __init__(self, target, compute=None):
+        """target: a CellGrid (append) or a scan_to_map.MapRegistration (ingest: routed by key range).
+        compute: the Voxelizer's ComputeShader, when it is on the target's device -- the staged voxels are then
+        resolved to points and appended on the device (a device copy of the point store is switched on; do this
+        before the map's first addPoints), and frameVoxelized is not used."""
         self.target = target
         self._batch = []
         self.points_fed = 0
         self.voxels_fed = 0
+        self.compute = compute
+        if compute is not None:
+            compute.keepPointStore(True)
+
+    def framesStagedOnDevice(self):
+        """Voxelizer._hand_off calls this instead of frameVoxelized per row when `compute` was given: the rows the
+        last stager dispatch staged, gathered from the device point store, go into the map in one append."""
+        ptr, n, rows = self.compute.stagedPointsDevice()
+        if n:
+            if hasattr(self.target, "ingest_device"):
+                self.target.ingest_device(ptr, n)
+            else:
+                self.target.append_device(ptr, n)
+        self.points_fed += n
+        self.voxels_fed += rows
+        return n
 
     def frameVoxelized(self, voxel_points, colors, separate_colors):
         """VoxelManager.frameVoxelized's signature; the colours are the renderer's business, not the map's."""

@@ -157,6 +157,12 @@ class HipMapBackend:
         self.held = self.grid.held
         return kept
 
+    def append_device(self, xyz_dev, n, first_id, slab=None):
+        slab3 = None if slab is None else (self.own_cell, slab[0], slab[1])
+        kept = self.grid.append_device(xyz_dev, n, first_id=first_id, slab=slab3)
+        self.held = self.grid.held
+        return kept
+
     def stream_context(self):
         return self._torch.cuda.stream(self.stream)
 
@@ -267,6 +273,14 @@ class MapRegistration:
         lo, hi = self.ranges[self.rank]
         kept = self.backend.append(pts, normals, self.total_points, slab=(lo, hi) if self.world > 1 else None)
         self.total_points += len(pts)
+        self.slab_points += kept
+        return kept
+
+    def ingest_device(self, xyz_dev, n):
+        """ingest() for n points already in this rank's device memory (n x 3 float64 at address xyz_dev)."""
+        lo, hi = self.ranges[self.rank]
+        kept = self.backend.append_device(xyz_dev, n, self.total_points, slab=(lo, hi) if self.world > 1 else None)
+        self.total_points += int(n)
         self.slab_points += kept
         return kept
 

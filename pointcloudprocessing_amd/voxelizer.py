@@ -127,6 +127,10 @@ class Voxelizer:
         that scans are registered against) is fed without one."""
         if self.voxman is None or (self.renderer is None and getattr(self.voxman, "needs_renderer", True)):
             return
+        if getattr(self.voxman, "compute", None) is not None and hasattr(self.voxman, "framesStagedOnDevice"):
+            if len(voxels_to_render):
+                self.voxman.framesStagedOnDevice()         # the device resolves the staged rows itself
+            return
         for v_slice in voxels_to_render:
             points, colors = self.getStoredPointsFromVoxelDataSlice(v_slice)
             self.voxman.frameVoxelized(points, colors, self.separate_colors)

@@ -446,6 +446,65 @@ def test_staged_voxels_of_the_voxelizer_accumulate_in_the_map(frames, tmp_path):
         cs.cleanup()
 
 
+def test_staged_voxels_reach_the_map_without_the_host(frames):
+    """The device copy of the point store: the rows a stager dispatch releases are resolved to points and appended
+    on the device (pcp_voxel_staged_points + pcp_grid_append_dev / _slab_dev).  Same map as the host gather of the
+    reference's hand-off (Voxelizer.py:130-133, :396-399) feeds -- ids, order, coordinates -- whole and as one
+    rank's slab of a split map."""
+    from pointcloudprocessing_amd import ComputeShader, MapSink, Voxelizer
+    from pointcloudprocessing_amd import scan_to_map as S
+    a, b = frames
+    cs = ComputeShader(maxPointsPerCloud=200000, maxScans=100)
+    grid_host, grid_dev = CellGrid(np.zeros((0, 3)), cell=0.5), CellGrid(np.zeros((0, 3)), cell=0.5)
+    seed = a[::50]
+    regs = [S.MapRegistration(seed, 1.0, rank=1, world=2, nn_cell=0.5) for _ in range(2)]
+    host_sinks = [MapSink(grid_host), MapSink(regs[0])]
+    dev_sinks = [MapSink(grid_dev, compute=cs), MapSink(regs[1], compute=cs)]
+    vox = Voxelizer(cs, None, voxman=dev_sinks[0])
+    plain = vox._hand_off
+
+    def both(rows):
+        for v_slice in rows:                                   # the reference's hand-off, on the host
+            pts, cols = vox.getStoredPointsFromVoxelDataSlice(v_slice)
+            for sink in host_sinks:
+                sink.frameVoxelized(pts, cols, False)
+        for sink in host_sinks:
+            sink.flush()
+        plain(rows)                                            # the device path into the whole map ...
+        if len(rows):
+            dev_sinks[1].framesStagedOnDevice()                # ... and into the rank's slab
+
+    vox._hand_off = both
+    try:
+        vox.init(0.5)
+        vox.separate_colors, vox.filter_outliers = False, False
+        for k in range(4):
+            vox.addPoints(a + np.array([0.0, 0.0, -0.33 * k]), None)
+        vox.stageAllRemaningVoxels()
+        assert dev_sinks[0].points_fed == host_sinks[0].points_fed > 100000
+        assert dev_sinks[0].voxels_fed >= host_sinks[0].voxels_fed > 1000      # the host sink skips empty rows
+        ih, xh = grid_host.sorted_points()
+        idv, xd = grid_dev.sorted_points()
+        assert np.array_equal(ih, idv) and np.array_equal(xh, xd)
+        assert grid_host.info()["cells"] == grid_dev.info()["cells"]
+        assert 0 < regs[0].slab_points == regs[1].slab_points < regs[0].total_points == regs[1].total_points
+        ih, xh = regs[0].backend.grid.sorted_points()
+        idv, xd = regs[1].backend.grid.sorted_points()
+        assert np.array_equal(ih, idv) and np.array_equal(xh, xd)
+        # a store that was not kept cannot resolve anything
+        cs2 = ComputeShader(maxPointsPerCloud=1000)
+        with pytest.raises(Exception, match="point store is off"):
+            cs2.stagedPointsDevice()
+        cs2.cleanup()
+    finally:
+        vox.cleanup()
+        for g in (grid_host, grid_dev):
+            g.cleanup()
+        for r in regs:
+            r.close()
+        cs.cleanup()
+
+
 def test_ingest_routed_by_key_range_equals_the_slab_of_the_whole(frames):
     """Two ranks' shares, one after the other on this GPU: each rank's slab grown by ingests (every rank is handed
     the same batch and keeps its part) equals its slab of the whole map."""
