@@ -37,6 +37,8 @@ struct SeqDecoded {       // rotated float64 point of frame f; targets also get 
     double* const* xyz;
     float4* const* a32;           // a32[f] == nullptr for the last frame (it is nobody's target)
     const double* place;          // per frame 12 doubles (rotation Q row-major, offset g), or nullptr
+    double* const* az;            // per frame: azimuth of every kept point about the origin (getScanLines :366-374)
+    double ox, oy, oz;
     double R[9];
     __device__ void operator()(int f, size_t i, size_t slot) const {
         const float4 p = raw[f][i];
@@ -54,26 +56,25 @@ struct SeqDecoded {       // rotated float64 point of frame f; targets also get 
         }
         double* out = xyz[f];
         out[3 * slot + 0] = rx; out[3 * slot + 1] = ry; out[3 * slot + 2] = rz;
+        // sphereProjectPoints about origin + (0, 0.127, 0), azimuth atan2(z, x) mapped to [0, 2 pi): once per point here,
+        // the ring-boundary passes below only compare neighbours
+        const double vx = rx - ox, vy = (ry - oy) - 0.127, vz = rz - oz;
+        const double mag = sqrt((vx * vx + vy * vy) + vz * vz);
+        double a = atan2(vz / mag, vx / mag);
+        if (a < 0.0) a += 6.283185307179586;
+        az[f][slot] = a;
         // ComputeShader.pad_points (:956-961) + the float32 cast of the upload
         if (a32[f]) a32[f][slot] = make_float4((float)rx, (float)ry, (float)rz, 0.0f);
     }
 };
 
 struct SeqWrap {          // ring boundary after point i of frame f (getScanLines :366-381)
-    const double* const* xyz;
+    const double* const* az;      // azimuths written by the decode
     const unsigned* n_pts;        // points kept per frame (device)
-    double ox, oy, oz;
     __device__ size_t count(int f) const { const unsigned n = n_pts[f]; return n < 2 ? 0 : (size_t)n - 1; }
-    __device__ double azimuth(const double* p, size_t i) const {
-        const double vx = p[3 * i + 0] - ox, vy = (p[3 * i + 1] - oy) - 0.127, vz = p[3 * i + 2] - oz;
-        const double mag = sqrt((vx * vx + vy * vy) + vz * vz);
-        double a = atan2(vz / mag, vx / mag);
-        if (a < 0.0) a += 6.283185307179586;
-        return a;
-    }
     __device__ bool operator()(int f, size_t i) const {
-        const double* p = xyz[f];
-        return fabs(azimuth(p, i + 1) - azimuth(p, i)) > 6.0;
+        const double* a = az[f];
+        return fabs(a[i + 1] - a[i]) > 6.0;
     }
 };
 
@@ -172,8 +173,7 @@ __global__ void k_seq_kept(const unsigned* __restrict__ counts, int stride, int 
 
 // Per pair p (target = frame p, source = frame p + 1): the scan-line table as preparePointPlane /
 // prepareLS would upload it (ComputeShader.py:571-585 pads to max_scans rows of (1, 1), :491-515 does
-// not), the sizes in the pair's three descriptors, its loop state.  One thread per pair: a table has at
-// most max_scans rows.  flags[p]: bit 0 = more ring ends than max_scans, bit 1 = target without a ring,
+// not), the sizes in the pair's three descriptors, its loop state.  One wave per pair.  flags[p]: bit 0 = more ring ends than max_scans, bit 1 = target without a ring,
 // bit 2 = empty source; such a pair is switched off (n_b = 0, done = 1) and reported by the collect call.
 struct SeqDescribe {
     const unsigned* n_pts; const unsigned* ring_counts; int ring_stride, ring_tiles;
@@ -184,8 +184,8 @@ struct SeqDescribe {
     const double* place; // per frame 12 doubles (rotation, offset), or nullptr
 };
 
-__global__ void k_seq_describe(const SeqDescribe D) {
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ void __launch_bounds__(64) k_seq_describe(const SeqDescribe D) {
+    const int p = blockIdx.x;             // one wave per pair: a row per lane, every load independent of the others
     if (p >= D.n_pairs) return;
     const unsigned n_a = D.n_pts[p], n_b = D.n_pts[p + 1];
     const unsigned found = D.ring_counts[(size_t)p * D.ring_stride + D.ring_tiles];
@@ -197,19 +197,22 @@ __global__ void k_seq_describe(const SeqDescribe D) {
     if (!flag) {
         int2* scan = D.scan[p];
         const unsigned* ends = D.ends[p];
-        unsigned begin = 0;
-        for (unsigned k = 0; k < found; ++k) {
-            scan[k] = make_int2((int)begin, (int)ends[k]);
-            begin = ends[k] + 1;
+        const int rows = D.pad_lines ? D.max_scans : (int)found;
+        for (int k = threadIdx.x; k < rows; k += 64) {
+            if (k < (int)found) scan[k] = make_int2(k == 0 ? 0 : (int)ends[k - 1] + 1, (int)ends[k]);
+            else scan[k] = make_int2(1, 1);
         }
-        Z = (int)found;
-        if (D.pad_lines) {
-            for (int k = (int)found; k < D.max_scans; ++k) scan[k] = make_int2(1, 1);
-            Z = D.max_scans;
+        Z = rows;
+        // Trailing rows equal to the row before them are padding copies (see set_target_impl): the search stops at the
+        // first of them.  Real rows begin at strictly increasing points, so only the (1, 1) padding repeats: the
+        // first padding row stays unless the last real row is (1, 1) itself.
+        Zs = Z;
+        if (D.pad_lines && (int)found < D.max_scans) {
+            const int last_begin = found == 1 ? 0 : (int)ends[found - 2] + 1, last_end = (int)ends[found - 1];
+            Zs = (last_begin == 1 && last_end == 1) ? (int)found : (int)found + 1;
         }
-        Zs = Z;          // trailing rows equal to the row before them are padding copies (see set_target_impl)
-        while (Zs > 1 && scan[Zs - 1].x == scan[Zs - 2].x && scan[Zs - 1].y == scan[Zs - 2].y) --Zs;
     }
+    if (threadIdx.x != 0) return;
     LsArgs& L = D.ls[p];
     L.n_a = flag ? 0 : (int)n_a; L.n_b = flag ? 0 : (int)n_b; L.Z = Z; L.Zs = Zs;
     L.skip_store_iter = D.last_iter;
@@ -261,9 +264,11 @@ struct pcp_seq {
     std::vector<pcp_ctx*> ctxs;                 // one per pair: target-side buffers, working copy, loop state
     std::vector<float4*> raw;                   // per frame
     std::vector<double*> xyz;
+    std::vector<double*> az;                    // per frame: azimuth of every kept point
     std::vector<unsigned*> ends;
     // device arrays of per-frame pointers / sizes
-    float4** raw_dev = nullptr; double** xyz_dev = nullptr; float4** a32_dev = nullptr; unsigned** ends_dev = nullptr;
+    float4** raw_dev = nullptr; double** xyz_dev = nullptr; double** az_dev = nullptr; float4** a32_dev = nullptr;
+    unsigned** ends_dev = nullptr;
     int2** scan_dev = nullptr;
     int* n_raw_dev = nullptr; int* n_raw_host[2] = {nullptr, nullptr};     // pinned mirrors, one per result slot
     // per-frame placements (12 doubles): one device copy per result slot too -- the describe kernel reads it after the
@@ -293,8 +298,9 @@ int pcp_seq_destroy(pcp_seq* s) {
     for (pcp_ctx* c : s->ctxs) { c->stream = c->own_stream; pcp_destroy(c); }
     for (float4* p : s->raw) if (p) (void)hipFree(p);
     for (double* p : s->xyz) if (p) (void)hipFree(p);
+    for (double* p : s->az) if (p) (void)hipFree(p);
     for (unsigned* p : s->ends) if (p) (void)hipFree(p);
-    void* dev[] = {s->raw_dev, s->xyz_dev, s->a32_dev, s->ends_dev, s->scan_dev, s->n_raw_dev, s->place_dev[0], s->place_dev[1], s->n_pts, s->keep_counts,
+    void* dev[] = {s->raw_dev, s->xyz_dev, s->az_dev, s->a32_dev, s->ends_dev, s->scan_dev, s->n_raw_dev, s->place_dev[0], s->place_dev[1], s->n_pts, s->keep_counts,
                    s->ring_counts, s->ls_dev, s->fin_dev, s->prep_dev, s->flags_dev, s->rec_dev};
     for (void* p : dev) if (p) (void)hipFree(p);
     for (int k = 0; k < 2; ++k) {
@@ -339,13 +345,14 @@ int pcp_seq_create(int device, int max_frames, int max_points, int max_scans, pc
         if (ok()) e = hipHostMalloc((void**)&s->place_host[k], (size_t)F * 12 * sizeof(double));
     }
     auto A = [&](void** p, size_t bytes) { if (ok()) e = hipMalloc(p, bytes); };
-    s->raw.assign(F, nullptr); s->xyz.assign(F, nullptr); s->ends.assign(P, nullptr);
+    s->raw.assign(F, nullptr); s->xyz.assign(F, nullptr); s->az.assign(F, nullptr); s->ends.assign(P, nullptr);
     for (int f = 0; f < F; ++f) {
         A((void**)&s->raw[f], (size_t)max_points * sizeof(float4));
         A((void**)&s->xyz[f], (size_t)max_points * 3 * sizeof(double));
+        A((void**)&s->az[f], (size_t)max_points * sizeof(double));
         if (f < P) A((void**)&s->ends[f], (size_t)max_scans * sizeof(unsigned));
     }
-    A((void**)&s->raw_dev, F * sizeof(void*)); A((void**)&s->xyz_dev, F * sizeof(void*));
+    A((void**)&s->raw_dev, F * sizeof(void*)); A((void**)&s->xyz_dev, F * sizeof(void*)); A((void**)&s->az_dev, F * sizeof(void*));
     A((void**)&s->a32_dev, F * sizeof(void*)); A((void**)&s->ends_dev, P * sizeof(void*)); A((void**)&s->scan_dev, P * sizeof(void*));
     A((void**)&s->n_raw_dev, F * sizeof(int)); A((void**)&s->n_pts, F * sizeof(unsigned));
     A((void**)&s->place_dev[0], (size_t)F * 12 * sizeof(double)); A((void**)&s->place_dev[1], (size_t)F * 12 * sizeof(double));
@@ -388,6 +395,7 @@ int pcp_seq_create(int device, int max_frames, int max_points, int max_scans, pc
     if (ok()) e = hipMemcpy(s->prep_dev, prep.data(), P * sizeof(PrepArgs), hipMemcpyHostToDevice);
     if (ok()) e = hipMemcpy(s->raw_dev, s->raw.data(), F * sizeof(void*), hipMemcpyHostToDevice);
     if (ok()) e = hipMemcpy(s->xyz_dev, s->xyz.data(), F * sizeof(void*), hipMemcpyHostToDevice);
+    if (ok()) e = hipMemcpy(s->az_dev, s->az.data(), F * sizeof(void*), hipMemcpyHostToDevice);
     if (ok()) e = hipMemcpy(s->a32_dev, a32.data(), F * sizeof(void*), hipMemcpyHostToDevice);
     if (ok()) e = hipMemcpy(s->ends_dev, s->ends.data(), P * sizeof(void*), hipMemcpyHostToDevice);
     if (ok()) e = hipMemcpy(s->scan_dev, scan.data(), P * sizeof(void*), hipMemcpyHostToDevice);
@@ -435,6 +443,7 @@ int pcp_seq_submit_placed(pcp_seq* s, const float* const* raw_xyzi, const int* n
     const SeqKeepFar keep{(const float4* const*)s->raw_dev, s->n_raw_dev, min_range};
     SeqDecoded dec;
     dec.raw = (const float4* const*)s->raw_dev; dec.xyz = s->xyz_dev; dec.a32 = s->a32_dev; dec.place = place;
+    dec.az = s->az_dev; dec.ox = origin3[0]; dec.oy = origin3[1]; dec.oz = origin3[2];
     memcpy(dec.R, R9, sizeof(dec.R));
     const dim3 tiles_f(s->tiles, F), tiles_p(s->tiles, P);
     hipLaunchKernelGGL(k_seq_count<SeqKeepFar>, tiles_f, dim3(FR_THREADS), 0, q, keep, s->keep_counts, s->stride);
@@ -444,7 +453,7 @@ int pcp_seq_submit_placed(pcp_seq* s, const float* const* raw_xyzi, const int* n
     PCP_CHECK(hipGetLastError());
     PCP_CHECK(hipEventRecord(s->decoded, q));
     s->decoded_pending = true;
-    const SeqWrap wrap{(const double* const*)s->xyz_dev, s->n_pts, origin3[0], origin3[1], origin3[2]};
+    const SeqWrap wrap{(const double* const*)s->az_dev, s->n_pts};
     const SeqRingEnd ring_end{s->ends_dev, (unsigned)s->max_scans};
     hipLaunchKernelGGL(k_seq_count<SeqWrap>, tiles_p, dim3(FR_THREADS), 0, q, wrap, s->ring_counts, s->stride);
     hipLaunchKernelGGL(k_seq_scan, dim3(P), dim3(1024), 0, q, s->ring_counts, s->stride, s->tiles);
@@ -455,7 +464,7 @@ int pcp_seq_submit_placed(pcp_seq* s, const float* const* raw_xyzi, const int* n
     D.n_pairs = P; D.max_scans = s->max_scans; D.pad_lines = (mode == PCP_MODE_PLANE) ? 1 : 0;
     D.last_iter = max_iter - 1;
     D.place = place;
-    hipLaunchKernelGGL(k_seq_describe, dim3(cdiv(P, 64)), dim3(64), 0, q, D);
+    hipLaunchKernelGGL(k_seq_describe, dim3(P), dim3(64), 0, q, D);
     PCP_CHECK(hipGetLastError());
     // origin as uploaded: np.resize(origin, (4,)) repeats, [ox, oy, oz, ox] (ComputeShader.py:436-437); it sits in the
     // descriptors' value half, which the host owns: refreshed only when it changes
