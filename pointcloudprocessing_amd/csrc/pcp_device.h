@@ -100,44 +100,33 @@ struct Target {
 // arithmetic with the one integer division hoisted: the absolute midpoint
 // (begin+end)/2 is reduced mod L once, every later step stays inside (-L, 2L)
 // and wraps with a compare.  exclude < 0 disables the 'test != pindex' clause.
+// One level of binaryScanCircleSearch for a lane whose ring has L >= 2 points starting at beg.
+__device__ __forceinline__ void search_level(const Target& T, const float4 ref, const int beg, const int L, int& idx, int& half) {
+    float c1, c2;
+    if (__any(idx == 0 || idx + 1 == L)) {        // some lane of the wave is at an end of its ring
+        const int i1 = (idx == 0) ? L - 1 : idx - 1;
+        const int i2 = (idx + 1 == L) ? 0 : idx + 1;
+        c1 = dot4(ld4i(T.ua, beg + i1), ref) + 1.0f;
+        c2 = dot4(ld4i(T.ua, beg + i2), ref) + 1.0f;
+    } else {                                      // both neighbours sit beside idx: one address
+        const gf4_t m = (gf4_t)((const char PCP_GLOBAL*)T.ua + ((unsigned)(beg + idx) << 4));
+        const pcp_f4 v1 = m[-1], v2 = m[1];
+        c1 = dot4(make_float4(v1.x, v1.y, v1.z, v1.w), ref) + 1.0f;
+        asm volatile("" : "+v"(c1));              // keeps the two sums from being interleaved lane-pairwise
+        c2 = dot4(make_float4(v2.x, v2.y, v2.z, v2.w), ref) + 1.0f;
+    }
+    // idx -+ half lies in (-L, 2L): of t, t + L and t - L exactly one is in [0, L), and read as
+    // unsigned numbers it is the smallest of the three
+    const unsigned t = (unsigned)((c1 > c2) ? idx - half : idx + half);
+    idx = (int)min(min(t, t + (unsigned)L), t - (unsigned)L);
+    half = (half + 1) >> 1;
+}
+
+// The +-CHECK window around position idx of a ring of L >= 2 points (binsearchAndCheck :142-156 /
+// closestDistinctOnLine, NormalShader.glsl:18-31); exclude < 0 disables the 'test != pindex' clause.
 template <int CHECK, bool EXCL>
-__device__ __forceinline__ void ring_window(const Target& T, const float4 q, const float4 ref,
-                                            const int beg, const int end, const int exclude,
-                                            int& best, float& mind) {
-    const int L = end - beg + 1;
-    mind = PCP_BIG;
-    if (L == 1) {
-        // runs == 0: the search returns begin + (begin+end)/2 untouched, and all
-        // 2*CHECK window slots are the ring's single point.
-        const int closest = beg + (beg + end) / 2;
-        best = min(closest, T.n_a - 1);
-        const float d = distsq(q, ld4i(T.a, beg));
-        if (d < mind && (!EXCL || beg != exclude)) { mind = d; best = beg; }
-        return;
-    }
-    int idx = ((beg + end) / 2) % L;
-    int half = L / 2;
-    const int runs = 32 - __clz(L - 1);           // exact ceil(log2(L)), L >= 2
-    for (int i = 0; i < runs; ++i) {
-        float c1, c2;
-        if (__any(idx == 0 || idx + 1 == L)) {        // some lane of the wave is at an end of its ring
-            const int i1 = (idx == 0) ? L - 1 : idx - 1;
-            const int i2 = (idx + 1 == L) ? 0 : idx + 1;
-            c1 = dot4(ld4i(T.ua, beg + i1), ref) + 1.0f;
-            c2 = dot4(ld4i(T.ua, beg + i2), ref) + 1.0f;
-        } else {                                      // both neighbours sit beside idx: one address
-            const gf4_t m = (gf4_t)((const char PCP_GLOBAL*)T.ua + ((unsigned)(beg + idx) << 4));
-            const pcp_f4 v1 = m[-1], v2 = m[1];
-            c1 = dot4(make_float4(v1.x, v1.y, v1.z, v1.w), ref) + 1.0f;
-            asm volatile("" : "+v"(c1));              // keeps the two sums from being interleaved lane-pairwise
-            c2 = dot4(make_float4(v2.x, v2.y, v2.z, v2.w), ref) + 1.0f;
-        }
-        // idx -+ half lies in (-L, 2L): of t, t + L and t - L exactly one is in [0, L), and read as
-        // unsigned numbers it is the smallest of the three
-        const unsigned t = (unsigned)((c1 > c2) ? idx - half : idx + half);
-        idx = (int)min(min(t, t + (unsigned)L), t - (unsigned)L);
-        half = (half + 1) >> 1;
-    }
+__device__ __forceinline__ void window_min(const Target& T, const float4 q, const int beg, const int L, const int idx,
+                                           const int exclude, int& best, float& mind) {
     best = beg + idx;
     if (idx >= CHECK && idx + CHECK <= L) {
         // The window does not wrap (all but the lanes within CHECK points of the ring's ends): its
@@ -185,6 +174,96 @@ __device__ __forceinline__ void ring_window(const Target& T, const float4 q, con
             const float d = distsq(q, ld4i(T.a, test));
             if (d < mind && (!EXCL || test != exclude)) { mind = d; best = test; }
         }
+    }
+}
+
+// A ring of a single point: runs == 0, the search returns begin + (begin+end)/2 untouched, and all
+// 2*CHECK window slots are the ring's single point.
+template <bool EXCL>
+__device__ __forceinline__ void single_point_ring(const Target& T, const float4 q, const int beg, const int end,
+                                                  const int exclude, int& best, float& mind) {
+    const int closest = beg + (beg + end) / 2;
+    best = min(closest, T.n_a - 1);
+    const float d = distsq(q, ld4i(T.a, beg));
+    if (d < mind && (!EXCL || beg != exclude)) { mind = d; best = beg; }
+}
+
+template <int CHECK, bool EXCL>
+__device__ __forceinline__ void ring_window(const Target& T, const float4 q, const float4 ref,
+                                            const int beg, const int end, const int exclude,
+                                            int& best, float& mind) {
+    const int L = end - beg + 1;
+    mind = PCP_BIG;
+    if (L == 1) {
+        single_point_ring<EXCL>(T, q, beg, end, exclude, best, mind);
+        return;
+    }
+    int idx = ((beg + end) / 2) % L;
+    int half = L / 2;
+    const int runs = 32 - __clz(L - 1);           // exact ceil(log2(L)), L >= 2
+    for (int i = 0; i < runs; ++i) search_level(T, ref, beg, L, idx, half);
+    window_min<CHECK, EXCL>(T, q, beg, L, idx, exclude, best, mind);
+}
+
+// ring_window on N rings for the same query at once: the N binary searches advance level by level
+// together in straight-line code, so their gathers are in flight together and the dependent chain is
+// that of the longest search instead of the sum; the windows follow one after the other.  Per ring the
+// same loads feed the same arithmetic as in ring_window, hence the same result.  live[k] == false
+// skips ring k (best[k] = -1); its (begin, end) must still name a valid ring (its loads are issued and
+// their results dropped, as are those of a lane whose search has fewer levels than the wave's longest).
+template <int N, int CHECK, bool EXCL>
+__device__ __forceinline__ void ring_windows(const Target& T, const float4 q, const float4 ref, const int2 (&se)[N],
+                                             const bool (&live)[N], const int exclude, int (&best)[N], float (&mind)[N]) {
+    int L[N], idx[N], half[N], runs[N];
+    int most = 0;
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        L[k] = se[k].y - se[k].x + 1;
+        mind[k] = PCP_BIG;
+        best[k] = -1;
+        const bool search = live[k] && L[k] >= 2;
+        idx[k] = search ? ((se[k].x + se[k].y) / 2) % L[k] : 0;
+        half[k] = L[k] / 2;
+        runs[k] = search ? 32 - __clz(L[k] - 1) : 0;
+        most = max(most, runs[k]);
+    }
+    for (int m = 1; m < 64; m <<= 1) most = max(most, __shfl_xor(most, m, 64));      // wave-uniform trip count
+    for (int i = 0; i < most; ++i) {
+        bool edge = false;
+#pragma unroll
+        for (int k = 0; k < N; ++k) edge = edge || idx[k] == 0 || idx[k] + 1 >= L[k];
+        pcp_f4 v1[N], v2[N];
+        if (__any(edge)) {                            // some lane is at an end of one of its rings
+#pragma unroll
+            for (int k = 0; k < N; ++k) {
+                const int i1 = (idx[k] == 0) ? L[k] - 1 : idx[k] - 1;
+                const int i2 = (idx[k] + 1 >= L[k]) ? 0 : idx[k] + 1;
+                v1[k] = *(gf4_t)((const char PCP_GLOBAL*)T.ua + ((unsigned)(se[k].x + i1) << 4));
+                v2[k] = *(gf4_t)((const char PCP_GLOBAL*)T.ua + ((unsigned)(se[k].x + i2) << 4));
+            }
+        } else {                                      // both neighbours sit beside idx: one address per ring
+#pragma unroll
+            for (int k = 0; k < N; ++k) {
+                const gf4_t m = (gf4_t)((const char PCP_GLOBAL*)T.ua + ((unsigned)(se[k].x + idx[k]) << 4));
+                v1[k] = m[-1];
+                v2[k] = m[1];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            float c1 = dot4(make_float4(v1[k].x, v1[k].y, v1[k].z, v1[k].w), ref) + 1.0f;
+            asm volatile("" : "+v"(c1));
+            const float c2 = dot4(make_float4(v2[k].x, v2[k].y, v2[k].z, v2[k].w), ref) + 1.0f;
+            const unsigned t = (unsigned)((c1 > c2) ? idx[k] - half[k] : idx[k] + half[k]);
+            const int next = (int)min(min(t, t + (unsigned)L[k]), t - (unsigned)L[k]);
+            if (i < runs[k]) { idx[k] = next; half[k] = (half[k] + 1) >> 1; }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        if (!live[k]) continue;
+        if (L[k] == 1) single_point_ring<EXCL>(T, q, se[k].x, se[k].y, exclude, best[k], mind[k]);
+        else window_min<CHECK, EXCL>(T, q, se[k].x, L[k], idx[k], exclude, best[k], mind[k]);
     }
 }
 

@@ -213,17 +213,19 @@ __device__ __forceinline__ void normals_body(const float4* __restrict__ a, const
     }
     const float4 q = a[i];
     const float4 ref = ua[i];   // == projectSpherePoint(points_a[i])
-    const int on_line = closest_distinct<5>(T, q, ref, i, ring);
+    // own ring, ring above, ring below: three searches for one query, run together (ring_windows).  An edge ring
+    // has one neighbour only (NormalShader.glsl:36-60); the missing one is not searched.
+    const bool has_above = ring > 0, has_below = ring < Z - 1;
+    const int2 se[3] = {s_scan[ring], s_scan[has_above ? ring - 1 : ring], s_scan[has_below ? ring + 1 : ring]};
+    const bool live[3] = {true, has_above, has_below};
+    int found[3];
+    float dist[3];
+    ring_windows<3, 5, true>(T, q, ref, se, live, i, found, dist);
+    const int on_line = found[0];
     int nxt;
-    if (ring == Z - 1) {
-        nxt = closest_distinct<5>(T, q, ref, i, ring - 1);
-    } else if (ring == 0) {
-        nxt = closest_distinct<5>(T, q, ref, i, ring + 1);
-    } else {
-        const int above = closest_distinct<5>(T, q, ref, i, ring - 1);
-        const int below = closest_distinct<5>(T, q, ref, i, ring + 1);
-        nxt = (distsq(q, a[below]) < distsq(q, a[above])) ? below : above;
-    }
+    if (!has_below) nxt = found[1];
+    else if (!has_above) nxt = found[2];
+    else nxt = (distsq(q, a[found[2]]) < distsq(q, a[found[1]])) ? found[2] : found[1];
     const float4 pl = a[on_line], pn = a[nxt];
     const float v1x = pl.x - q.x, v1y = pl.y - q.y, v1z = pl.z - q.z;
     const float v2x = pn.x - q.x, v2y = pn.y - q.y, v2z = pn.z - q.z;
