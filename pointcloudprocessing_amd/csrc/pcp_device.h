@@ -528,4 +528,38 @@ __device__ __forceinline__ float wave_tree_sum(float x) {
     return x;
 }
 
+// wave_tree_sum of all PCP_NVAL values of a wave at once; returns for lane k < PCP_NVAL the sum of value k (what
+// lane 0 of wave_tree_sum(v[k]) holds), 0 for the other lanes.  The half-wave swap that step 32 needs anyway can
+// exchange the halves of TWO values, after which one addition performs step 32 for both (each left in one half of
+// the register), and the row swap of step 16 does the same with two such registers: 7 registers then hold four
+// values each, one per row of 16 lanes, and go through the four in-row steps together.  Every value still sees
+// exactly the additions x[l] + x[l + s], s = 32 ... 1, of the shader's tree; only unrelated values share a register.
+__device__ __forceinline__ float wave_tree_sum_all(const float (&v)[PCP_NVAL], const int lane) {
+    typedef unsigned pcp_u2 __attribute__((ext_vector_type(2)));
+    static_assert(PCP_NVAL <= 28, "seven registers of four values");
+    float h[14];                    // h[m] = values 2m (lanes 0-31) and 2m + 1 (lanes 32-63) after step 32
+#pragma unroll
+    for (int m = 0; m < 14; ++m) {
+        const float lo = v[2 * m];
+        const float hi = (2 * m + 1 < PCP_NVAL) ? v[2 * m + 1] : 0.0f;
+        const pcp_u2 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(lo), __float_as_uint(hi), false, false);
+        h[m] = __uint_as_float(r.x) + __uint_as_float(r.y);       // [lo.low + lo.high | hi.low + hi.high]
+    }
+    float mine = 0.0f;
+    const int row_of = ((lane & 1) << 1) | ((lane >> 1) & 1);      // value 4n + c sits in row {0, 2, 1, 3}[c] of register n
+#pragma unroll
+    for (int n = 0; n < 7; ++n) {
+        // rows before: h[2n] = [a0 a1 | b0 b1], h[2n+1] = [c0 c1 | d0 d1]; after the swap [a0 c0 b0 d0] and [a1 c1 b1 d1]
+        const pcp_u2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(h[2 * n]), __float_as_uint(h[2 * n + 1]), false, false);
+        float x = __uint_as_float(r.x) + __uint_as_float(r.y);
+        x = x + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x108, 0xf, 0xf, true));   // row_shl:8
+        x = x + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x104, 0xf, 0xf, true));   // row_shl:4
+        x = x + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x102, 0xf, 0xf, true));   // row_shl:2
+        x = x + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x101, 0xf, 0xf, true));   // row_shl:1
+        const float got = __shfl(x, row_of << 4, 64);             // first lane of the row that holds this lane's value
+        mine = ((lane >> 2) == n && lane < PCP_NVAL) ? got : mine;
+    }
+    return mine;
+}
+
 }  // namespace pcp

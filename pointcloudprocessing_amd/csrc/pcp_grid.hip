@@ -891,14 +891,7 @@ __global__ void __launch_bounds__(PCP_BLOCK) k_map_ls(const MapLsArgs A) {
     const int lane = threadIdx.x & 63;
     const size_t wave = i >> 6;
     if ((wave << 6) < A.m) {
-#pragma unroll
-        for (int k = 0; k < PCP_NVAL; ++k) v[k] = wave_tree_sum(v[k]);
-        float mine = 0.0f;
-#pragma unroll
-        for (int k = 0; k < PCP_NVAL; ++k) {
-            const float vk = __shfl(v[k], 0, 64);
-            mine = (lane == k) ? vk : mine;
-        }
+        const float mine = wave_tree_sum_all(v, lane);      // lane k: value k of the wave's tree sum
         if (lane < PCP_PSTRIDE) A.partials[wave * PCP_PSTRIDE + lane] = mine;
     }
 }
@@ -927,14 +920,7 @@ k_map_tiles(const GridView G, const float4* __restrict__ normals, const double* 
     const int lane = threadIdx.x & 63;
     const size_t wave = i >> 6;
     if ((wave << 6) < m) {
-#pragma unroll
-        for (int k = 0; k < PCP_NVAL; ++k) v[k] = wave_tree_sum(v[k]);
-        float mine = 0.0f;
-#pragma unroll
-        for (int k = 0; k < PCP_NVAL; ++k) {
-            const float vk = __shfl(v[k], 0, 64);
-            mine = (lane == k) ? vk : mine;
-        }
+        const float mine = wave_tree_sum_all(v, lane);      // lane k: value k of the wave's tree sum
         if (lane < PCP_PSTRIDE) partials[wave * PCP_PSTRIDE + lane] = mine;
     }
 }

@@ -346,14 +346,7 @@ __device__ __forceinline__ void ls_body(const LsArgs& A, char* smem, const unsig
     const int lane = threadIdx.x & 63;
     const int wave = i >> 6;               // == shader workgroup id
     if ((wave << 6) < n_b) {               // wave-uniform
-#pragma unroll
-        for (int k = 0; k < PCP_NVAL; ++k) v[k] = wave_tree_sum(v[k]);
-        float mine = 0.0f;       // lane k takes value k from lane 0: one 128-byte store per wave
-#pragma unroll
-        for (int k = 0; k < PCP_NVAL; ++k) {
-            const float vk = __shfl(v[k], 0, 64);
-            mine = (lane == k) ? vk : mine;
-        }
+        const float mine = wave_tree_sum_all(v, lane);      // lane k: value k of the wave's tree sum
         if (lane < PCP_PSTRIDE) partials[(size_t)wave * PCP_PSTRIDE + lane] = mine;
     }
 }
@@ -441,14 +434,7 @@ __global__ void __launch_bounds__(256) k_ls_quad(const LsArgs A) {
         if (MODE == PCP_MODE_POINT) ls_point_values(pa, q, d, v);
         else ls_plane_values(pa, q, ld4(as_global(A.normals), nn), d, v);
     }
-#pragma unroll
-    for (int k = 0; k < PCP_NVAL; ++k) v[k] = wave_tree_sum(v[k]);
-    float mine = 0.0f;
-#pragma unroll
-    for (int k = 0; k < PCP_NVAL; ++k) {
-        const float vk = __shfl(v[k], 0, 64);
-        mine = (qi == k) ? vk : mine;
-    }
+    const float mine = wave_tree_sum_all(v, qi);      // lane k: value k of the wave's tree sum
     if (qi < PCP_PSTRIDE) A.partials[(size_t)blockIdx.x * PCP_PSTRIDE + qi] = mine;
 }
 
