@@ -509,31 +509,16 @@ __device__ __forceinline__ void ls_plane_values(const float4 pa, const float4 pb
     }
 }
 
-// The pairwise tree of ParalellHBSum.glsl:158-164 over the 64 lanes of a wave:
-// after the six steps lane 0 holds exactly sdata[0] of the shader.
-// Only the lanes below s matter at step s, and they read lanes below 2s, so what the other lanes
-// receive is irrelevant.  Steps 32 and 16 are the gfx950 half-wave and row swaps (lane l of the
-// second result holds lane l + 32, resp. l + 16 for the even rows, of the operand), steps 8..1 are
-// row shifts applied inside the addition (DPP): no LDS traffic at all.
-__device__ __forceinline__ float wave_tree_sum(float x) {
-    typedef unsigned pcp_u2 __attribute__((ext_vector_type(2)));
-    pcp_u2 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
-    x = x + __uint_as_float(r.y);
-    r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
-    x = x + __uint_as_float(r.y);
-    x = x + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x108, 0xf, 0xf, true));   // row_shl:8
-    x = x + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x104, 0xf, 0xf, true));   // row_shl:4
-    x = x + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x102, 0xf, 0xf, true));   // row_shl:2
-    x = x + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x101, 0xf, 0xf, true));   // row_shl:1
-    return x;
-}
-
-// wave_tree_sum of all PCP_NVAL values of a wave at once; returns for lane k < PCP_NVAL the sum of value k (what
-// lane 0 of wave_tree_sum(v[k]) holds), 0 for the other lanes.  The half-wave swap that step 32 needs anyway can
-// exchange the halves of TWO values, after which one addition performs step 32 for both (each left in one half of
-// the register), and the row swap of step 16 does the same with two such registers: 7 registers then hold four
-// values each, one per row of 16 lanes, and go through the four in-row steps together.  Every value still sees
-// exactly the additions x[l] + x[l + s], s = 32 ... 1, of the shader's tree; only unrelated values share a register.
+// The pairwise tree of ParalellHBSum.glsl:158-164 over the 64 lanes of a wave, for all PCP_NVAL values at
+// once: x[l] += x[l + s] for the lanes l < s, s = 32, 16, 8, 4, 2, 1, after which lane 0 holds sdata[0] of the
+// shader.  Returns for lane k < PCP_NVAL the sum of value k, 0 for the other lanes.
+// Only the lanes below s matter at step s, and they read lanes below 2s, so what the other lanes receive is
+// irrelevant.  Steps 32 and 16 are the gfx950 half-wave and row swaps: the swap that step 32 needs can exchange
+// the halves of TWO values, after which one addition performs step 32 for both (each left in one half of the
+// register), and the row swap of step 16 does the same with two such registers.  Seven registers then hold four
+// values each, one per row of 16 lanes, and go through steps 8 ... 1 together as row shifts applied inside the
+// addition (DPP).  Every value sees exactly the additions of the shader's tree; only unrelated values share a
+// register.  No LDS traffic but the final gather of the 27 sums.
 __device__ __forceinline__ float wave_tree_sum_all(const float (&v)[PCP_NVAL], const int lane) {
     typedef unsigned pcp_u2 __attribute__((ext_vector_type(2)));
     static_assert(PCP_NVAL <= 28, "seven registers of four values");
