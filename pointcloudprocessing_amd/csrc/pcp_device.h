@@ -55,6 +55,9 @@ __device__ __forceinline__ float4 unit_sphere(const float4 p, const float4 o) {
 #ifndef PCP_WIN_GROUP
 #define PCP_WIN_GROUP 7           // window loads in flight per lane
 #endif
+#ifndef PCP_WRAP_GROUP
+#define PCP_WRAP_GROUP 4          // the same for a window that wraps around its ring's end (each slot needs its own index)
+#endif
 #define PCP_AZ_BINS 64            // azimuth bins of the per-ring elevation table
 // 0.999 * (sin(0.99 * 2 pi / PCP_AZ_BINS) - 1e-5)^2, rounded down: squared sine of the smallest
 // azimuth gap between a query and a target point two or more bins away, with the margins of
@@ -158,13 +161,31 @@ __device__ __forceinline__ void window_min(const Target& T, const float4 q, cons
         }
         if (slot >= 0) best = first + slot;
     } else if (L >= CHECK) {
-#pragma unroll
-        for (int i = -CHECK; i < CHECK; ++i) {
-            int t = idx + i;
+        // The window wraps around an end of the ring.  Few lanes come here, but the whole wave waits for them (the
+        // rings all begin at the same azimuth, so the waves that straddle it pay this in every ring they visit): the
+        // loads are grouped exactly as above, each slot's index with its own wrap.
+        auto slot_index = [&](const int k) {
+            int t = idx + k - CHECK;
             t = (t < 0) ? t + L : ((t >= L) ? t - L : t);
-            const int test = beg + t;
-            const float d = distsq(q, ld4i(T.a, test));
-            if (d < mind && (!EXCL || test != exclude)) { mind = d; best = test; }
+            return beg + t;
+        };
+#pragma unroll
+        for (int g = 0; g < 2 * CHECK; g += PCP_WRAP_GROUP) {
+            pcp_f4 p[PCP_WRAP_GROUP];
+#pragma unroll
+            for (int i = 0; i < PCP_WRAP_GROUP; ++i)
+                if (g + i < 2 * CHECK) p[i] = *(gf4_t)((const char PCP_GLOBAL*)T.a + ((unsigned)slot_index(g + i) << 4));
+#pragma unroll
+            for (int i = 0; i < PCP_WRAP_GROUP; ++i)
+                if (g + i < 2 * CHECK) asm volatile("" : "+v"(p[i]));
+#pragma unroll
+            for (int i = 0; i < PCP_WRAP_GROUP; ++i) {
+                if (g + i < 2 * CHECK) {
+                    const int test = slot_index(g + i);
+                    const float d = distsq(q, make_float4(p[i].x, p[i].y, p[i].z, p[i].w));
+                    if (d < mind && (!EXCL || test != exclude)) { mind = d; best = test; }
+                }
+            }
         }
     } else {
         for (int i = -CHECK; i < CHECK; ++i) {
