@@ -42,7 +42,8 @@ struct pcp_voxel_state {
     bool keep_store = false;
     float4* store = nullptr; size_t store_cap = 0, store_n = 0;
     int last_staged = 0;     // rows the last pcp_voxel_stage call staged
-    unsigned* staged_off = nullptr;          // stage_rows + 2: exclusive scan of the staged rows' point counts, total, error flag
+    unsigned* staged_off = nullptr;          // staged_off_rows + 2: exclusive scan of the staged rows' point counts, total, error flag
+    int staged_off_rows = 0;
     double* staged_xyz = nullptr; size_t staged_cap = 0;
 };
 
@@ -832,7 +833,12 @@ int pcp_voxel_staged_points(pcp_ctx* c, const double** xyz_dev, size_t* n_points
     const int rows = v->last_staged;
     if (rows == 0) return 0;
     if (!v->stage || rows > v->stage_rows) return pcp_fail("no staging buffer for %d rows", rows);
-    if (!v->staged_off) PCP_CHECK(hipMalloc(&v->staged_off, ((size_t)v->stage_rows + 2) * sizeof(unsigned)));
+    if (!v->staged_off || v->staged_off_rows < v->stage_rows) {      // follows the staging buffer (max_staging may change)
+        if (v->staged_off) PCP_CHECK(hipFree(v->staged_off));
+        v->staged_off = nullptr; v->staged_off_rows = 0;
+        PCP_CHECK(hipMalloc(&v->staged_off, ((size_t)v->stage_rows + 2) * sizeof(unsigned)));
+        v->staged_off_rows = v->stage_rows;
+    }
     hipLaunchKernelGGL(k_staged_offsets, dim3(1), dim3(1024), 0, c->stream, v->stage, rows, v->stage_width, v->staged_off);
     PCP_CHECK(hipGetLastError());
     unsigned total = 0;
