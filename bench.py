@@ -601,8 +601,8 @@ def main():
                          "avg_launch_us": res["avg_launch_s"] * 1e6, "launches_timed": res["ls_launches"],
                          "algorithmic_bytes_per_launch": res["alg_bytes"],
                          "limited_by": "not HBM: chains of dependent 16-byte gathers served by L1/L2. Counters of this workload "
-                                       "(profiles/r02_seq_pmc_*.csv): texture-address units 77 % busy on average and 89 % on the busiest, "
-                                       "vector ALU 78 % busy, waves waiting 71 % of their life, L2 hit rate 86 %; `traffic` (L2 misses: "
+                                       "(profiles/r02_seq_pmc_*.csv): texture-address units 79 % busy on average and 91 % on the busiest, "
+                                       "vector ALU 73 % busy, waves waiting 72 % of their life, L2 hit rate 86 %; `traffic` (L2 misses: "
                                        "every launch streams its float64 working copy, hints and each pair's target once) is 3x the "
                                        "algorithmic bytes, which count a target once per pair, not once per launch"},
             "cpu_baseline": cpu,
