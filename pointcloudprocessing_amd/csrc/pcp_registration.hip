@@ -249,7 +249,13 @@ k_normals(const float4* __restrict__ a, const float4* __restrict__ ua, const int
     normals_body(a, ua, scan, stat, n_a, Z, o, normals, smem, blockIdx.x);
 }
 
-__global__ void __launch_bounds__(PCP_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) k_normals_batch(const PrepArgs* __restrict__ all) {
+// Resident waves per SIMD of the batched normals: with the three searches of a point in flight together the kernel
+// wants 68 registers; at 8 waves (64 registers) five of them spill.  Measured per launch of 64 targets: 8 waves 542 us,
+// 7 waves 506 us, 6 waves 534 us.
+#ifndef PCP_NORMALS_WAVES
+#define PCP_NORMALS_WAVES 7
+#endif
+__global__ void __launch_bounds__(PCP_BLOCK) __attribute__((amdgpu_waves_per_eu(PCP_NORMALS_WAVES, PCP_NORMALS_WAVES))) k_normals_batch(const PrepArgs* __restrict__ all) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     unsigned pair, block;
     pair_and_block(pair, block);
