@@ -424,10 +424,47 @@ def extras(raws, device):
                      "grid_build_ms": float(info["build_ms"]), "nn_ms": float(qms), "nn_queries_per_s": len(q) / (qms * 1e-3)})
     grid.cleanup()
     cs.cleanup()
+    out["ringless_pt2pl"] = ringless_leg(device)
     out["voxel_sweep"] = {"what": "configs[2]: %d synthetic LiDAR-like points (10 sweeps): Voxelizer.addPoints per sweep, Morton radix "
                                   "sort + cell table of the whole cloud, exact NN of the cloud jittered by 5 cm" % len(cloud),
                           "rows": rows}
     return out
+
+
+def ringless_leg(device):
+    """configs[1]: a model cloud without scan rings against itself under a rigid transform + Gaussian noise, point-to-plane
+    ICP with normals estimated from the model.  golden-tiger.ply is not part of the reference checkout: PCP_BENCH_PLY names
+    a file to use instead of the synthetic stand-in (a bumpy closed surface of the same order of size)."""
+    from pointcloudprocessing_amd.map_output import read_ply_ascii, read_ply_binary
+    path = os.environ.get("PCP_BENCH_PLY")
+    if path and os.path.exists(path):
+        cloud = read_ply_ascii(path)
+        cloud = (read_ply_binary(path) if cloud is None else cloud)[:, :3].astype(np.float64)
+        name = os.path.basename(path)
+    else:
+        rng = np.random.default_rng(7)
+        u, v = rng.uniform(0, 2 * np.pi, 400000), np.arccos(rng.uniform(-1, 1, 400000))
+        r = 1.0 + 0.15 * np.sin(3 * u) * np.sin(4 * v) + 0.08 * np.cos(5 * v + u)
+        cloud = np.column_stack([1.3 * r * np.sin(v) * np.cos(u), r * np.cos(v), 0.8 * r * np.sin(v) * np.sin(u)])
+        name = "synthetic closed surface, 400 k points (stand-in for golden-tiger.ply)"
+    extent = float(np.linalg.norm(cloud.max(axis=0) - cloud.min(axis=0)))
+    R = lidar.rotation_xyz(0.02, -0.01, 0.015)
+    t = np.array([0.05, -0.02, 0.03]) * extent / 3.0
+    rng = np.random.default_rng(0)
+    moved = (R @ cloud.T).T + t + rng.normal(0.0, 0.002 * extent, cloud.shape)
+    icp = PointcloudIcpContainer(None)
+    radius = 0.03 * extent
+    times = []
+    for _ in range(3):
+        c0 = time.perf_counter()
+        _, t_opt, R_opt = icp.align_ringless_pt2pl(cloud, moved, radius, iterations=20, viewpoint=cloud.mean(axis=0) + 10 * extent)
+        times.append(time.perf_counter() - c0)
+    # p <- R_opt p - t_opt undoes p' = R p + t: R_opt = R^T, t_opt = R^T t
+    return {"what": "configs[1]: ring-less model (%s, %d points) against R * model + t + N(0, (0.2 %% of its extent)^2): exact "
+                    "neighbours on the cell grid, normals from the model (PCA of the ball), point-to-plane <= 20 iterations; "
+                    "host arrays in, pose out" % (name, len(cloud)),
+            "ms": float(min(times) * 1e3), "rotation_error": float(np.abs(R_opt - R.T).max()),
+            "translation_error_over_extent": float(np.abs(t_opt - R.T @ t).max() / extent), "parity": "unpinned (no counterpart in the reference)"}
 
 
 def scan_to_map_leg(raws, rank, world, device, dist, exchange):
