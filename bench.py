@@ -89,24 +89,14 @@ def traffic_for(workload, pairs, n_b):
     return None
 
 
-def issue_pipes(workload):
-    """How busy the two issue pipes the fused kernel leans on were, from the committed counter passes of this workload
-    (rocprofv3 --pmc cannot run inside this process): vector ALU = SQ_ACTIVE_INST_VALU x 4 / (GRBM_GUI_ACTIVE / 8 XCDs x
-    1024 SIMDs), texture-address units = TA_BUSY / (GRBM_GUI_ACTIVE / 8)."""
-    import csv
-    if workload != "sequence":
-        return None
-    try:
-        def means(name):
-            with open(os.path.join(ROOT, "profiles", name)) as f:
-                return {r["Counter_Name"]: float(r["Mean"]) for r in csv.DictReader(f) if "k_ls_batch" in r["Kernel_Name"]}
-        sq, ta = means("r02_seq_pmc_sq.csv"), means("r02_seq_pmc_ta.csv")
-        return {"valu_busy": sq["SQ_ACTIVE_INST_VALU"] * 4 / (sq["GRBM_GUI_ACTIVE"] / 8 * 1024),
-                "ta_busy_avg": ta["TA_BUSY_avr"] / (ta["GRBM_GUI_ACTIVE"] / 8), "ta_busy_max": ta["TA_BUSY_max"] / (ta["GRBM_GUI_ACTIVE"] / 8),
-                "waves_waiting": sq["SQ_WAIT_ANY"] / sq["SQ_WAVE_CYCLES"],
-                "source": "profiles/r02_seq_pmc_sq.csv, profiles/r02_seq_pmc_ta.csv (separate rocprofv3 --pmc passes of this workload)"}
-    except (OSError, KeyError, ZeroDivisionError):
-        return None
+def issue_pipes(workload, pairs):
+    """How busy the two issue pipes the fused kernel leans on were, from the committed summary of the counter passes of
+    this workload (rocprofv3 --pmc cannot run inside this process; tools/profile_r02.sh takes them)."""
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_issue_pipes.json")))[::-1]:
+        d = json.load(open(f))
+        if (d.get("workload"), d.get("pairs_per_launch")) == (workload, pairs):
+            return {k: d[k] for k in ("valu_busy", "ta_busy_avg", "ta_busy_max", "waves_waiting", "l2_hit_rate", "how", "source")}
+    return None
 
 
 # ----------------------------------------------------------------------------------- workloads
@@ -657,7 +647,7 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": res["traffic"],
                          "avg_launch_us": res["avg_launch_s"] * 1e6, "launches_timed": res["ls_launches"],
                          "algorithmic_bytes_per_launch": res["alg_bytes"],
-                         "issue_pipes": issue_pipes(args.workload),
+                         "issue_pipes": issue_pipes(args.workload, args.pairs),
                          "limited_by": "not HBM: chains of dependent 16-byte gathers served by L1/L2. Counters of this workload "
                                        "(profiles/r02_seq_pmc_*.csv): texture-address units 79 % busy on average and 91 % on the busiest, "
                                        "vector ALU 73 % busy, waves waiting 72 % of their life, L2 hit rate 86 %; `traffic` (L2 misses: "

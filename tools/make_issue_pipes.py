@@ -1,0 +1,25 @@
+"""Summary of the SQ / TA / L2 counter passes of the fused kernel as the JSON bench.py quotes (CSV files do not travel to the
+GPU box):  python tools/make_issue_pipes.py pmc_sq.csv pmc_ta.csv pmc_l2.csv out.json"""
+import csv
+import json
+import sys
+
+
+def means(path):
+    with open(path) as f:
+        return {r["Counter_Name"]: float(r["Mean"]) for r in csv.DictReader(f) if "k_ls_batch" in r["Kernel_Name"]}
+
+
+sq, ta, l2 = means(sys.argv[1]), means(sys.argv[2]), means(sys.argv[3])
+out = {"kernel": "k_ls_batch<1>", "workload": "sequence", "pairs_per_launch": 64,
+       "valu_busy": sq["SQ_ACTIVE_INST_VALU"] * 4 / (sq["GRBM_GUI_ACTIVE"] / 8 * 1024),
+       "ta_busy_avg": ta["TA_BUSY_avr"] / (ta["GRBM_GUI_ACTIVE"] / 8), "ta_busy_max": ta["TA_BUSY_max"] / (ta["GRBM_GUI_ACTIVE"] / 8),
+       "waves_waiting": sq["SQ_WAIT_ANY"] / sq["SQ_WAVE_CYCLES"],
+       "l2_hit_rate": l2["TCC_HIT_sum"] / (l2["TCC_HIT_sum"] + l2["TCC_MISS_sum"]),
+       "valu_instructions_per_wave": sq["SQ_INSTS_VALU"] / sq["SQ_WAVES"],
+       "vmem_read_instructions_per_wave": sq["SQ_INSTS_VMEM_RD"] / sq["SQ_WAVES"],
+       "how": "vector ALU = SQ_ACTIVE_INST_VALU x 4 / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs); texture-address units = TA_BUSY / "
+              "(GRBM_GUI_ACTIVE / 8); waiting = SQ_WAIT_ANY / SQ_WAVE_CYCLES",
+       "source": "profiles/r02_seq_pmc_sq.csv, r02_seq_pmc_ta.csv, r02_seq_pmc_l2.csv (separate rocprofv3 --pmc passes of bench.py's "
+                 "sequence workload, tools/profile_r02.sh)"}
+json.dump(out, open(sys.argv[4], "w"), indent=1)

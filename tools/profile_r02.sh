@@ -25,6 +25,7 @@ for t in fetch:f:pmc_FETCH_SIZE write:w:pmc_WRITE_SIZE cf:f:calib_FETCH_SIZE cw:
   python tools/rocpd_export.py pmc $O/$d/${o}_results.db $O/$name.csv
 done
 python tools/make_traffic.py $O/bench_line.json $O/pmc_FETCH_SIZE.csv $O/pmc_WRITE_SIZE.csv $O/calib_FETCH_SIZE.csv $O/calib_WRITE_SIZE.csv $O/traffic.json
+python tools/make_issue_pipes.py $O/pmc_sq.csv $O/pmc_ta.csv $O/pmc_l2.csv $O/issue_pipes.json
 python tools/kstats.py $O/kernel_stats.csv > $O/kstats.txt; sed -n 1,14p $O/kstats.txt
 cat $O/calib_FETCH_SIZE.csv $O/calib_WRITE_SIZE.csv
 grep k_ls_batch $O/pmc_sq.csv $O/pmc_ta.csv $O/pmc_l2.csv
