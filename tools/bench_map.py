@@ -1,6 +1,7 @@
 """Scan-to-map leg on one GPU: a map tiled from synthetic sweeps along a straight
 trajectory, one 120k-point scan registered against it (point-to-point, exact neighbours within 0.4 m).
-    python tools/bench_map.py [n_sweeps] [quick]      (quick: without the sweep over cell sizes)"""
+    python tools/bench_map.py [n_sweeps] [quick|ingest]      (quick: without the sweep over cell sizes;
+    ingest: the same map grown from its first sweeps by appends of 20 sweeps at a time, then the same registration)"""
 import os
 import sys
 import time
@@ -39,6 +40,27 @@ g.set_source(scan)
 ms = min(g.query(return_kernel_ms=True, distance_upper_bound=0.4)[2] for _ in range(3))
 print(f"bounded NN of the scan: {ms * 1e3:.1f} us = {len(scan) / ms / 1e3:.0f} M queries/s")
 reg.close()
+if len(sys.argv) > 2 and sys.argv[2] == "ingest":
+    step = 20
+    t0 = time.perf_counter()
+    grown = S.MapRegistration(np.vstack(parts[:step]), 0.5, nn_cell=0.15)
+    first_wall = time.perf_counter() - t0
+    walls, dev = [], []
+    for k0 in range(step, sweeps, step):
+        batch = np.vstack(parts[k0:k0 + step])
+        t0 = time.perf_counter()
+        grown.ingest(batch)
+        walls.append(time.perf_counter() - t0)
+        dev.append(grown.backend.grid.info()["build_ms"])
+    print(f"grown by ingests: first {step} sweeps {first_wall * 1e3:.0f} ms, then {len(walls)} appends of {step} sweeps "
+          f"({len(batch)} points): wall incl. upload median {np.median(walls) * 1e3:.1f} ms, last {walls[-1] * 1e3:.1f} ms; "
+          f"table rebuild on the device last {dev[-1]:.1f} ms; total {first_wall + sum(walls):.2f} s, "
+          f"{grown.backend.grid.info()['points']} points")
+    t2, R2, dx2, conv2 = grown.register(scan, S.MODE_POINT, 0.4, max_iter=10, check_every=0)
+    same = dx2.shape == dx.shape and np.array_equal(dx2.view(np.uint32), dx.view(np.uint32))
+    print(f"registration against the grown map: steps bit-equal to the built map's: {same}")
+    grown.close()
+    sys.exit(0)
 if len(sys.argv) > 2 and sys.argv[2] == "quick":
     sys.exit(0)
 from pointcloudprocessing_amd.cell_grid import CellGrid  # noqa: E402
