@@ -208,6 +208,14 @@ int pcp_voxel_counts_read(pcp_ctx* ctx, int first_row, int n_rows, int32_t* coun
 int pcp_voxel_stage(pcp_ctx* ctx, float* voxel_stat, int stat_rows, int stored, int max_points,
                     int filter_outliers, int stage_everything, int max_staging,
                     int32_t* counter16, int32_t* stage_out);
+/* pcp_voxel_stage with the statistics kept on the device between calls instead of uploaded and read back every frame
+ * (16 bytes per voxel each way in prepareDispatchVoxelStager, ComputeShader.py:776-780, :826-830): rows the device has
+ * not seen yet start as (0.5, 0, 0, 0), the statistics of a voxel that does not exist (Voxelizer.initVoxels,
+ * Voxelizer.py:382-388); pcp_voxel_stage itself leaves what it uploaded resident, pcp_voxel_reset forgets everything.
+ * pcp_voxel_stat_read copies the first `rows` rows (rows x 4 floats) to the host. */
+int pcp_voxel_stage_resident(pcp_ctx* ctx, int stat_rows, int stored, int max_points, int filter_outliers,
+                             int stage_everything, int max_staging, int32_t* counter16, int32_t* stage_out);
+int pcp_voxel_stat_read(pcp_ctx* ctx, int rows, float* voxel_stat);
 /* A device copy of the Voxelizer's global point store (added_points, filled by handleAddingPoints,
  * Voxelizer.py:398-425): while switched on, every pcp_voxelize* call also keeps its points at
  * [begin_index, begin_index + n) of a device array (16 bytes per point, doubling).  Switch it on before a map's

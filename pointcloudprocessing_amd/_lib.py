@@ -61,6 +61,8 @@ SIGNATURES = {
     "pcp_voxelize_xyz": (C.c_int, [_ctx, _f32p, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, _i32p, C.c_int, _f32p]),
     "pcp_voxelize_rows": (C.c_int, [_ctx, _f32p, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, _i32p, C.c_int, _f32p]),
     "pcp_voxel_stage": (C.c_int, [_ctx, _f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _i32p, _i32p]),
+    "pcp_voxel_stage_resident": (C.c_int, [_ctx, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _i32p, _i32p]),
+    "pcp_voxel_stat_read": (C.c_int, [_ctx, C.c_int, _f32p]),
     "pcp_voxel_store_enable": (C.c_int, [_ctx, C.c_int]),
     "pcp_voxel_staged_points": (C.c_int, [_ctx, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), _i32p]),
     "pcp_grid_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),

@@ -46,6 +46,7 @@ class ComputeShader:
         self._frame = None           # device frame of prepareTargetOnDevice, made on first use
         self._n_source = None        # points of the float64 source IcpBatch.upload_sources sent last
         self._voxel_resident = None  # voxel count of a map whose device copy is the authority, else None
+        self.resident_statistics = False  # the stager's statistics stay on the device between dispatches
         self.reallocate_out(np.array([maxPointsPerCloud, maxPointsPerCloud, 0, 0]))
 
     # ------------------------------------------------------------------ helpers
@@ -245,6 +246,7 @@ class ComputeShader:
         vi = np.ascontiguousarray(voxel_index, dtype=np.int32)
         check(self._lib.pcp_voxel_index_upload(self._ctx, i32p(vi), len(vi)))
         self._voxel_resident = None           # the host copy is the authority again
+        self.resident_statistics = False
 
     def fullBufferVoxelData(self, voxel_data):
         """:842-845"""
@@ -259,6 +261,7 @@ class ComputeShader:
         check(self._lib.pcp_voxel_reset(self._ctx))
         check(self._lib.pcp_voxel_reserve(self._ctx, int(rows), int(max_points)))
         self._voxel_resident = 0
+        self.resident_statistics = False        # a Voxelizer that reads its statistics lazily switches this on
 
     def insertUnknownVoxels(self, max_points):
         """Voxelizer.storeUnknownPoints (Voxelizer.py:170-306) on the device for the unknown points of the
@@ -329,16 +332,26 @@ class ComputeShader:
         if voxel_statistics.dtype != np.float32 or not voxel_statistics.flags.c_contiguous:
             raise PcpError("voxel_statistics must be a C-contiguous float32 array")
         counter = np.zeros((1, 16), dtype=np.int32)
-        check(self._lib.pcp_voxel_stage(self._ctx, f32p(voxel_statistics), len(voxel_statistics),
-                                        int(stored_voxel_num), int(max_points), int(bool(filter_outliers)),
-                                        int(bool(stage_everything)), int(max_staging), i32p(counter),
-                                        i32p(self.voxel_stage_out)))
+        if self.resident_statistics:
+            # the statistics stay on the device (readVoxelStatistics fetches them); voxel_statistics only gives the row count
+            check(self._lib.pcp_voxel_stage_resident(self._ctx, len(voxel_statistics), int(stored_voxel_num), int(max_points),
+                                                     int(bool(filter_outliers)), int(bool(stage_everything)), int(max_staging),
+                                                     i32p(counter), i32p(self.voxel_stage_out)))
+        else:
+            check(self._lib.pcp_voxel_stage(self._ctx, f32p(voxel_statistics), len(voxel_statistics),
+                                            int(stored_voxel_num), int(max_points), int(bool(filter_outliers)),
+                                            int(bool(stage_everything)), int(max_staging), i32p(counter),
+                                            i32p(self.voxel_stage_out)))
         staged = int(counter[0][0])
         if debug:
             return voxel_statistics, self.voxel_stage_out, counter
         if staged > 0:
             return voxel_statistics, self.voxel_stage_out[:staged]
         return voxel_statistics, []
+
+    def readVoxelStatistics(self, out):
+        """The device's statistics rows into out ((rows, 4) float32, C-contiguous), for resident_statistics."""
+        check(self._lib.pcp_voxel_stat_read(self._ctx, len(out), f32p(out)))
 
     def keepPointStore(self, on=True):
         """Keep a device copy of the Voxelizer's global point store (every dispatched cloud at its begin_index), so

@@ -22,6 +22,7 @@ struct pcp_voxel_state {
     int4* table = nullptr;   int table_rows = 0, table_valid = 0;   // capacity / rows of the last upload
     int* data = nullptr;     int data_rows = 0, data_width = 0;
     float4 *stat = nullptr, *stat_in = nullptr;   int stat_rows = 0;
+    int stat_valid = 0;      // rows of `stat` that hold statistics (resident mode); rows behind them are made (0.5, 0, 0, 0)
     int* stage = nullptr;    int stage_rows = 0, stage_width = 0;
     int* unknown = nullptr;  int unknown_cap = 0;
     float4* pts = nullptr;   float4* debug = nullptr;   int pts_cap = 0;
@@ -420,6 +421,12 @@ __global__ void __launch_bounds__(256) k_staged_gather(const int* __restrict__ s
     }
 }
 
+// Statistics of voxels that do not exist yet: probability 0.5, nothing else (Voxelizer.initVoxels, Voxelizer.py:382-388).
+__global__ void k_stat_init(float4* __restrict__ stat, int first, int rows) {
+    const int i = first + blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < rows) stat[i] = make_float4(0.5f, 0.0f, 0.0f, 0.0f);
+}
+
 int use(pcp_ctx* c) {
     if (!c) return pcp_fail("null context");
     PCP_CHECK(hipSetDevice(c->device));
@@ -601,6 +608,7 @@ int pcp_voxel_reset(pcp_ctx* c) {
     if (v->data) PCP_CHECK(hipFree(v->data));
     if (v->store) PCP_CHECK(hipFree(v->store));
     v->store = nullptr; v->store_cap = v->store_n = 0; v->last_staged = 0;
+    v->stat_valid = 0;
     v->table = nullptr; v->table_rows = v->table_valid = 0;
     v->data = nullptr;  v->data_rows = v->data_width = 0;
     v->last_unknown = -1;
@@ -760,19 +768,32 @@ int pcp_voxel_counts_read(pcp_ctx* c, int first_row, int n_rows, int32_t* counts
     return 0;
 }
 
-int pcp_voxel_stage(pcp_ctx* c, float* voxel_stat, int stat_rows, int stored, int max_points, int filter_outliers,
-                    int stage_everything, int max_staging, int32_t* counter16, int32_t* stage_out) {
+// voxel_stat == nullptr: the statistics stay on the device between calls (resident mode).
+static int stage_impl(pcp_ctx* c, float* voxel_stat, int stat_rows, int stored, int max_points, int filter_outliers,
+                      int stage_everything, int max_staging, int32_t* counter16, int32_t* stage_out) {
     if (int e = use(c)) return e;
     pcp_voxel_state* v = c->vox;
-    if (!voxel_stat || !counter16) return pcp_fail("null argument");
+    if (!counter16) return pcp_fail("null argument");
     if (stat_rows < 1 || max_staging < 1 || max_points < 2) return pcp_fail("bad sizes");
     if (stored < 0 || stored > v->table_valid) return pcp_fail("stored = %d, resident table has %d rows", stored, v->table_valid);
     if (stored > 0 && (!v->data || max_points != v->data_width))
         return pcp_fail("voxel data not resident with row width %d", max_points);
     if (stat_rows > v->stat_rows) {
-        int c1 = v->stat_rows, c2 = v->stat_rows;
-        if (int e = grow(&v->stat, &c1, (size_t)stat_rows, false, c->stream)) return e;
-        if (int e = grow(&v->stat_in, &c2, (size_t)stat_rows, false, c->stream)) return e;
+        // the resident statistics survive the growth
+        float4 *bigger = nullptr, *bigger_in = nullptr;
+        PCP_CHECK(hipMalloc(&bigger, (size_t)stat_rows * sizeof(float4)));
+        hipError_t e = hipMalloc(&bigger_in, (size_t)stat_rows * sizeof(float4));
+        if (e == hipSuccess && v->stat_valid > 0)
+            e = hipMemcpyAsync(bigger, v->stat, (size_t)v->stat_valid * sizeof(float4), hipMemcpyDeviceToDevice, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) {
+            (void)hipFree(bigger);
+            if (bigger_in) (void)hipFree(bigger_in);
+            return pcp_fail("growing the voxel statistics: %s", hipGetErrorString(e));
+        }
+        if (v->stat) (void)hipFree(v->stat);
+        if (v->stat_in) (void)hipFree(v->stat_in);
+        v->stat = bigger; v->stat_in = bigger_in;
         v->stat_rows = stat_rows;
     }
     if (max_staging != v->stage_rows || max_points != v->stage_width) {   // allocated once, zeroed (:765-770)
@@ -786,7 +807,14 @@ int pcp_voxel_stage(pcp_ctx* c, float* voxel_stat, int stat_rows, int stored, in
     }
     int host_counter[16] = {0, max_staging, max_points, stored, stage_everything ? 1 : 0, filter_outliers ? 0 : 1};
     PCP_CHECK(hipMemcpyAsync(v->counter, host_counter, sizeof(host_counter), hipMemcpyHostToDevice, c->stream));
-    PCP_CHECK(hipMemcpyAsync(v->stat, voxel_stat, (size_t)stat_rows * sizeof(float4), hipMemcpyHostToDevice, c->stream));
+    if (voxel_stat) {
+        PCP_CHECK(hipMemcpyAsync(v->stat, voxel_stat, (size_t)stat_rows * sizeof(float4), hipMemcpyHostToDevice, c->stream));
+        v->stat_valid = stat_rows;
+    } else if (v->stat_valid < stat_rows) {
+        hipLaunchKernelGGL(k_stat_init, dim3(cdiv(stat_rows - v->stat_valid, 256)), dim3(256), 0, c->stream, v->stat, v->stat_valid, stat_rows);
+        PCP_CHECK(hipGetLastError());
+        v->stat_valid = stat_rows;
+    }
     PCP_CHECK(hipMemcpyAsync(v->stat_in, v->stat, (size_t)stat_rows * sizeof(float4), hipMemcpyDeviceToDevice, c->stream));
     if (stored > 0) {
         hipLaunchKernelGGL(k_voxel_stage, dim3(cdiv(stored, 256)), dim3(256), 0, c->stream, v->table, stored, v->data,
@@ -795,7 +823,7 @@ int pcp_voxel_stage(pcp_ctx* c, float* voxel_stat, int stat_rows, int stored, in
         PCP_CHECK(hipGetLastError());
     }
     PCP_CHECK(hipMemcpyAsync(host_counter, v->counter, sizeof(host_counter), hipMemcpyDeviceToHost, c->stream));
-    PCP_CHECK(hipMemcpyAsync(voxel_stat, v->stat, (size_t)stat_rows * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
+    if (voxel_stat) PCP_CHECK(hipMemcpyAsync(voxel_stat, v->stat, (size_t)stat_rows * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
     PCP_CHECK(hipStreamSynchronize(c->stream));
     for (int i = 0; i < 16; ++i) counter16[i] = host_counter[i];
     const int staged = host_counter[0];
@@ -806,6 +834,29 @@ int pcp_voxel_stage(pcp_ctx* c, float* voxel_stat, int stat_rows, int stored, in
         PCP_CHECK(hipMemcpyAsync(stage_out, v->stage, (size_t)staged * max_points * sizeof(int), hipMemcpyDeviceToHost, c->stream));
         PCP_CHECK(hipStreamSynchronize(c->stream));
     }
+    return 0;
+}
+
+int pcp_voxel_stage(pcp_ctx* c, float* voxel_stat, int stat_rows, int stored, int max_points, int filter_outliers,
+                    int stage_everything, int max_staging, int32_t* counter16, int32_t* stage_out) {
+    if (!voxel_stat) return pcp_fail("null argument");
+    return stage_impl(c, voxel_stat, stat_rows, stored, max_points, filter_outliers, stage_everything, max_staging, counter16, stage_out);
+}
+
+int pcp_voxel_stage_resident(pcp_ctx* c, int stat_rows, int stored, int max_points, int filter_outliers, int stage_everything,
+                             int max_staging, int32_t* counter16, int32_t* stage_out) {
+    return stage_impl(c, nullptr, stat_rows, stored, max_points, filter_outliers, stage_everything, max_staging, counter16, stage_out);
+}
+
+int pcp_voxel_stat_read(pcp_ctx* c, int rows, float* voxel_stat) {
+    if (int e = use(c)) return e;
+    pcp_voxel_state* v = c->vox;
+    if (!voxel_stat || rows < 0) return pcp_fail("bad argument");
+    // rows the device has not seen yet read as the statistics of a voxel that does not exist: (0.5, 0, 0, 0)
+    const int have = rows < v->stat_valid ? rows : v->stat_valid;
+    if (have > 0) PCP_CHECK(hipMemcpyAsync(voxel_stat, v->stat, (size_t)have * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
+    for (int i = have; i < rows; ++i) { voxel_stat[4 * i] = 0.5f; voxel_stat[4 * i + 1] = voxel_stat[4 * i + 2] = voxel_stat[4 * i + 3] = 0.0f; }
+    PCP_CHECK(hipStreamSynchronize(c->stream));
     return 0;
 }
 

@@ -29,6 +29,7 @@ class Voxelizer:
         self.voxel_index = None           # (M, 4) int32: vx, vy, vz, data row; sorted; grows x2
         self._rows_stale = False
         self.voxel_data = None            # (M, max_points) int32: [0] count, [1:] point ids
+        self._stats_stale = False
         self.voxel_stats = None           # (M, 4) float32, by data row
         self.stored_voxels = None
 
@@ -61,6 +62,23 @@ class Voxelizer:
         self._voxel_data = value
         self._rows_stale = False
 
+    # The statistics likewise: the reference uploads them to every stager dispatch and reads them back (16 bytes per
+    # voxel each way per frame); kept on the device, the host copy is fetched when somebody looks at it.
+    @property
+    def voxel_stats(self):
+        if self._stats_stale and self._voxel_stats is not None:
+            self.compute.readVoxelStatistics(self._voxel_stats)
+            self._stats_stale = False
+        return self._voxel_stats
+
+    @voxel_stats.setter
+    def voxel_stats(self, value):
+        self._voxel_stats = value
+        self._stats_stale = False
+        # statistics assigned from outside while a map is live: the host copy is the authority from here on
+        if getattr(self, "inited", False) and getattr(self.compute, "resident_statistics", False):
+            self.compute.resident_statistics = False
+
     def _pull_rows(self):
         rows = len(self.voxel_index)
         if len(self._voxel_data) < rows:        # rows past stored_voxels are zero, on the device too
@@ -83,6 +101,7 @@ class Voxelizer:
         if hasattr(self.compute, "voxelReserve"):
             self.compute.voxelReserve(len(self.voxel_index), self.max_points)
             self.realloc_needed = False
+            self.compute.resident_statistics = True     # fresh map: every voxel starts from the default statistics
         self.inited = True
 
     def initVoxels(self, init_size=100):
@@ -113,12 +132,24 @@ class Voxelizer:
             prev_stored_voxels=self.prev_stored_voxels, debug=False)
         if hasattr(self.compute, "insertUnknownVoxels"):
             self._rows_stale = True           # the device appended to its rows; the host copy is read back on demand
-        self.voxel_stats, voxels_to_render = self.compute.prepareDispatchVoxelStager(
-            self.voxel_index, self.stored_voxels, self.max_points, self.voxel_stats,
-            filter_outliers=self.filter_outliers, stage_everything=False)
+        voxels_to_render = self._stage(False)
         self.realloc_needed, self.prev_stored_voxels = self.storeUnknownPoints(unknown_points, printt)
         self.last_run_realloc = self.realloc_needed
         self._hand_off(voxels_to_render)
+
+    def _stage(self, everything):
+        """One stager dispatch (:116-119, :141-152) -> the staged rows.  With the statistics resident on the device the
+        host array only tells the dispatch how many rows there are."""
+        resident = bool(getattr(self.compute, "resident_statistics", False))
+        stats = self._voxel_stats if resident else self.voxel_stats
+        out, rows = self.compute.prepareDispatchVoxelStager(
+            self.voxel_index, self.stored_voxels, self.max_points, stats,
+            filter_outliers=self.filter_outliers, stage_everything=everything)
+        if resident:
+            self._stats_stale = True
+        else:
+            self.voxel_stats = out
+        return rows
 
     def _hand_off(self, voxels_to_render):
         """:130-133 -- the points of every voxel staged by this dispatch go to the voxel manager.  The
@@ -149,9 +180,7 @@ class Voxelizer:
         """:139-165 -- stage until nothing comes back, then ten flush passes (a voxel
         recovered by its neighbours is only staged by the NEXT dispatch)."""
         def one_pass():
-            self.voxel_stats, rows = self.compute.prepareDispatchVoxelStager(
-                self.voxel_index, self.stored_voxels, self.max_points, self.voxel_stats,
-                filter_outliers=self.filter_outliers, stage_everything=True)
+            rows = self._stage(True)
             self._hand_off(rows)
             return rows
         while True:
@@ -188,9 +217,12 @@ class Voxelizer:
             old, used = self._voxel_data, self.stored_voxels
             self._voxel_data = np.zeros((2 * len(old), old.shape[1]), dtype=old.dtype)
             self._voxel_data[:used] = old[:used]
-        fresh = np.zeros_like(self.voxel_stats)
-        fresh[:, 0] = 0.5
-        self.voxel_stats = np.vstack([self.voxel_stats, fresh])
+        if self._stats_stale:                # the device holds the statistics: only the size of the host copy changes
+            self._voxel_stats = np.zeros((2 * len(self._voxel_stats), 4), dtype=np.float32)
+        else:
+            fresh = np.zeros_like(self._voxel_stats)
+            fresh[:, 0] = 0.5
+            self._voxel_stats = np.vstack([self._voxel_stats, fresh])
 
     def storeUnknownPoints(self, unknown_points, printt=False):
         """:170-306 -> (was_realloc, prev_stored_voxels).  Creates one voxel per
