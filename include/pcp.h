@@ -209,7 +209,7 @@ int pcp_voxel_stage(pcp_ctx* ctx, float* voxel_stat, int stat_rows, int stored, 
                     int filter_outliers, int stage_everything, int max_staging,
                     int32_t* counter16, int32_t* stage_out);
 /* pcp_voxel_stage with the statistics kept on the device between calls instead of uploaded and read back every frame
- * (16 bytes per voxel each way in prepareDispatchVoxelStager, ComputeShader.py:776-780, :826-830): rows the device has
+ * (16 bytes per voxel each way in prepareDispatchVoxelStager, ComputeShader.py:777-778, :809-811): rows the device has
  * not seen yet start as (0.5, 0, 0, 0), the statistics of a voxel that does not exist (Voxelizer.initVoxels,
  * Voxelizer.py:382-388); pcp_voxel_stage itself leaves what it uploaded resident, pcp_voxel_reset forgets everything.
  * pcp_voxel_stat_read copies the first `rows` rows (rows x 4 floats) to the host. */
