@@ -261,6 +261,7 @@ class ComputeShader:
         check(self._lib.pcp_voxel_reset(self._ctx))
         check(self._lib.pcp_voxel_reserve(self._ctx, int(rows), int(max_points)))
         self._voxel_resident = 0
+        self.voxel_map_epoch = getattr(self, "voxel_map_epoch", 0) + 1      # a new map: mirrors of the old one are void
         self.resident_statistics = False        # a Voxelizer that reads its statistics lazily switches this on
 
     def insertUnknownVoxels(self, max_points):

@@ -30,6 +30,7 @@ class Voxelizer:
         self._rows_stale = False
         self.voxel_data = None            # (M, max_points) int32: [0] count, [1:] point ids
         self._stats_stale = False
+        self._map_epoch = None
         self.voxel_stats = None           # (M, 4) float32, by data row
         self.stored_voxels = None
 
@@ -67,6 +68,9 @@ class Voxelizer:
     @property
     def voxel_stats(self):
         if self._stats_stale and self._voxel_stats is not None:
+            if getattr(self.compute, "voxel_map_epoch", None) != self._map_epoch:
+                raise RuntimeError("the device's voxel map has been replaced (another Voxelizer took this ComputeShader): "
+                                   "its statistics can no longer be fetched")
             self.compute.readVoxelStatistics(self._voxel_stats)
             self._stats_stale = False
         return self._voxel_stats
@@ -102,6 +106,7 @@ class Voxelizer:
             self.compute.voxelReserve(len(self.voxel_index), self.max_points)
             self.realloc_needed = False
             self.compute.resident_statistics = True     # fresh map: every voxel starts from the default statistics
+            self._map_epoch = getattr(self.compute, "voxel_map_epoch", None)
         self.inited = True
 
     def initVoxels(self, init_size=100):

@@ -335,3 +335,33 @@ def test_transposed_clouds_are_fed_as_coordinate_rows(compute):
     assert all(np.array_equal(x, y) for x, y in zip(a[2], b[2]))
     assert np.array_equal(a[3], b[3]) and np.array_equal(a[4], b[4]) and np.all(a[4] == 255.0)
     assert np.array_equal(a[3], np.vstack(kitti_pair()).astype(np.float32))
+
+
+def test_statistics_stay_on_the_device_and_are_fetched_on_access(compute):
+    """The stager's statistics are not uploaded and read back per frame when the map lives on the device: the host
+    array is filled when it is looked at, equals what the per-frame transfers of the reference's protocol give, and
+    a mirror whose map has been replaced on the device refuses to be read."""
+    rng = np.random.default_rng(3)
+    clouds = [rng.uniform(-12, 12, (30000, 3)) * [1, 0.1, 1] for _ in range(4)]
+    lazy = Voxelizer(compute, None)
+    lazy.init(0.5)
+    lazy.filter_outliers = True
+    for c in clouds:
+        lazy.addPoints(c, None)
+    assert compute.resident_statistics and lazy._stats_stale
+    got = lazy.voxel_stats.copy()                       # fetched here
+    assert not lazy._stats_stale and got.shape[1] == 4
+    n = lazy.stored_voxels
+    eager = Voxelizer(compute, None)
+    eager.init(0.5)
+    compute.resident_statistics = False                 # the reference's protocol: up and down with every dispatch
+    eager.filter_outliers = True
+    for c in clouds:
+        eager.addPoints(c, None)
+    assert eager.stored_voxels == n and not eager._stats_stale
+    assert np.array_equal(got[:n].view(np.uint32), eager.voxel_stats[:n].view(np.uint32)) and np.all(got[n:, 0] == 0.5)
+    assert np.any(got[:n, 1] > 1.0)                     # counts and running maxima have been written
+    lazy._stats_stale = True                            # as if it had not been read before the second map was made
+    with pytest.raises(RuntimeError, match="has been replaced"):
+        lazy.voxel_stats
+    eager.cleanup()
