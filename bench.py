@@ -45,12 +45,14 @@ GOLD = os.path.join(ROOT, "tests", "golden")
 
 # ----------------------------------------------------------------------------------- inputs
 def real_frames():
-    """The twelve raw sweeps (N, 4) float32; a synthetic drive of the same shape when the fixtures are absent."""
-    pair, seq = os.path.join(GOLD, "kitti_pair.npz"), os.path.join(GOLD, "kitti_seq.npz")
+    """The thirty raw sweeps (N, 4) float32; a synthetic drive of the same shape when the fixtures are absent."""
+    pair, seq, seq2 = (os.path.join(GOLD, n) for n in ("kitti_pair.npz", "kitti_seq.npz", "kitti_seq2.npz"))
     if os.path.exists(pair) and os.path.exists(seq):
         g = np.load(pair)
         raws = [g["raw0"], g["raw1"]] + lidar.unpack_raw_frames(np.load(seq))
-        name = "kitti 2011_09_26 frames 0000000000-0000000011 (fixtures), consecutive pairs"
+        if os.path.exists(seq2):
+            raws += lidar.unpack_raw_frames(np.load(seq2))
+        name = "kitti 2011_09_26 frames 0000000000-%010d (fixtures), consecutive pairs" % (len(raws) - 1)
     else:
         back = lidar.aligning_rotation().T
         raws = [(back @ lidar.synthetic_scan(k, pose_t=np.array([0.0, 0.0, -0.33 * k])).T).T.astype(np.float32)

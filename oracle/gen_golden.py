@@ -6,6 +6,8 @@ Needs /root/reference (read-only).  Three kinds of vectors:
   kitti_pair.npz   data: raw xyz of sample_data velodyne frames 0000000000 / 0000000001
   kitti_seq.npz    data: raw xyz of frames 0000000002 ... 0000000011 (packed losslessly, lidar.pack_raw_frames);
                    with kitti_pair.npz the first twelve frames, enough to cross the reference's 10-frame reset
+  kitti_seq2.npz   data: frames 0000000012 ... 0000000029 packed the same way: with the two above all 30 sweeps of
+                   sample_data (29 consecutive pairs, two replacements of the reference cloud)
   ref_kat.npz      outputs of the reference's OWN importable CPU functions
                    (PointcloudIcpContainer, PointcloudAlignment), the known
                    answers that pin the restatement in oracle/np_oracle.py
@@ -43,7 +45,7 @@ def kitti_pair():
     return raw
 
 
-def kitti_seq(first=2, last=11):
+def kitti_seq(first=2, last=11, name="kitti_seq.npz"):
     from pointcloudprocessing_amd import lidar
     d = os.path.join(REF, "sample_data/velodyne_points/data")
     raw = [np.fromfile(os.path.join(d, f"{i:010d}.bin"), dtype=np.float32).reshape(-1, 4)[:, :3].copy()
@@ -53,7 +55,7 @@ def kitti_seq(first=2, last=11):
         assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), "packing is not lossless for this frame"
     packed["first_frame"] = np.int64(first)
     packed["raw_sha"] = np.array([sha(r) for r in raw])
-    np.savez_compressed(os.path.join(OUT, "kitti_seq.npz"), **packed)
+    np.savez_compressed(os.path.join(OUT, name), **packed)
 
 
 def ref_kat(raw):
@@ -327,6 +329,7 @@ if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     raw = kitti_pair()
     kitti_seq()
+    kitti_seq(12, 29, "kitti_seq2.npz")
     frames = ref_kat(raw)
     if "--no-arena" not in sys.argv:
         ref_arena()

@@ -44,3 +44,11 @@ def kitti_sequence_raw():
     seq = golden("kitti_seq.npz")
     assert int(seq["first_frame"]) == 2
     return [g["raw0"], g["raw1"]] + lidar.unpack_raw_frames(seq)
+
+
+@functools.lru_cache(maxsize=None)
+def kitti_all_raw():
+    """Raw xyz (float32) of all thirty sample_data velodyne frames 0000000000 ... 0000000029."""
+    more = golden("kitti_seq2.npz")
+    assert int(more["first_frame"]) == 12
+    return kitti_sequence_raw() + lidar.unpack_raw_frames(more)
