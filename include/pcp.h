@@ -146,6 +146,18 @@ int pcp_upload_source_dev(pcp_ctx* ctx, const double* b_xyz_dev, int n_b);
 int pcp_icp_launch(pcp_ctx* ctx, int mode, int max_iter, float tol, int full_iter);
 int pcp_icp_fetch(pcp_ctx* ctx, float* dx_trace, float* hb_trace, int* iters,
                   int* converged, double* b_out);
+/* The pose the finished loop returns to its caller, PointcloudIcpContainer.full_pt2pt (:84-100) / full_pt2pl
+ * (:118-140): the 10x10x10 tracking grid of getUniformGrid (:429-438) moved by every applied step (applyIcpStep
+ * :320-322, float64) and uniform_optimal_icp (:333-347) between the moved and the original grid -- means, 3x3
+ * cross-covariance, R_opt = U V^T of its singular value decomposition (no determinant fix), t_opt = mean' - R_opt
+ * mean -- computed on the device behind the loop (one more kernel on the context's stream).  The caller applies
+ * p <- R_opt p - t_opt (EnvironmentConstructor.py:101-102).  t_opt3: 3 float64, R_opt9: row-major 3x3 float64.
+ * Waits for the loop.  Also valid per context after pcp_batch_icp_launch. */
+int pcp_icp_fetch_pose(pcp_ctx* ctx, double* t_opt3, double* R_opt9);
+/* The same extraction for steps the caller holds: dx_steps = n_steps rows of 6 float32 (t, then the three angles),
+ * applied in order to the tracking grid (rotation() of PointcloudAlignment.py:229-261 per step), then
+ * uniform_optimal_icp.  n_steps = 0 gives the identity. */
+int pcp_pose_from_steps(pcp_ctx* ctx, const float* dx_steps, int n_steps, double* t_opt3, double* R_opt9);
 /* Recompute unit vectors (+ normals when with_normals) and reset hints for the
  * target already resident in ctx: the kernel half of prepare*, no upload. */
 int pcp_prepare_resident(pcp_ctx* ctx, int with_normals);
@@ -489,6 +501,11 @@ int pcp_seq_submit_placed(pcp_seq* seq, const float* const* raw_xyzi, const int*
  * a scan line, an empty source, singular normal equations. */
 int pcp_seq_collect(pcp_seq* seq, int ticket, float* dx_trace, int dx_stride_iters, int* iters, int* converged,
                     int* n_points);
+/* pcp_seq_collect that also returns every pair's pose as full_pt2pl / full_pt2pt return it (see pcp_icp_fetch_pose),
+ * computed on the device behind the loops and fetched with the steps in the same copy: t_opt receives 3, R_opt 9
+ * (row-major) float64 per pair; any output pointer may be NULL. */
+int pcp_seq_collect_poses(pcp_seq* seq, int ticket, double* t_opt, double* R_opt, float* dx_trace, int dx_stride_iters,
+                          int* iters, int* converged, int* n_points);
 /* As pcp_batch_profile_enable / pcp_batch_profile_read: HIP events on the compute stream around every fused
  * NN + least-squares launch of the submissions made while enabled; read (after collecting) the summed
  * duration of the last collected submission's launches that did work, their number and the source points

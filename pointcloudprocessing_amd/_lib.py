@@ -52,6 +52,8 @@ SIGNATURES = {
     "pcp_upload_source_dev": (C.c_int, [_ctx, C.c_void_p, C.c_int]),
     "pcp_icp_launch": (C.c_int, [_ctx, C.c_int, C.c_int, C.c_float, C.c_int]),
     "pcp_icp_fetch": (C.c_int, [_ctx, _f32p, _f32p, _i32p, _i32p, _f64p]),
+    "pcp_icp_fetch_pose": (C.c_int, [_ctx, _f64p, _f64p]),
+    "pcp_pose_from_steps": (C.c_int, [_ctx, _f32p, C.c_int, _f64p, _f64p]),
     "pcp_prepare_resident": (C.c_int, [_ctx, C.c_int]),
     "pcp_voxel_index_upload": (C.c_int, [_ctx, _i32p, C.c_int]),
     "pcp_voxel_data_upload": (C.c_int, [_ctx, _i32p, C.c_int, C.c_int]),
@@ -136,6 +138,7 @@ SIGNATURES = {
     "pcp_seq_submit_placed": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), _i32p, C.c_int, C.c_float, _f64p, _f64p, _f64p, C.c_int,
                                         C.c_int, C.c_float, C.c_int, _i32p]),
     "pcp_seq_collect": (C.c_int, [C.c_void_p, C.c_int, _f32p, C.c_int, _i32p, _i32p, _i32p]),
+    "pcp_seq_collect_poses": (C.c_int, [C.c_void_p, C.c_int, _f64p, _f64p, _f32p, C.c_int, _i32p, _i32p, _i32p]),
     "pcp_seq_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "pcp_seq_profile_read": (C.c_int, [C.c_void_p, _f32p, _i32p, C.POINTER(C.c_longlong)]),
     "pcp_host_alloc": (C.c_int, [C.c_size_t, C.POINTER(C.c_void_p)]),

@@ -240,6 +240,21 @@ class ComputeShader:
         k = iters.value
         return dx[:k], bool(conv.value), (hb[:k] if want_hb else None), out
 
+    def fetchPose(self):
+        """(t_opt (3,), R_opt (3, 3)) float64 of the loop icpRun ran last, as full_pt2pt / full_pt2pl return them
+        (PointcloudIcpContainer.py:140, :333-347): tracking grid and Kabsch extraction on the device."""
+        t_opt, R_opt = np.zeros(3), np.zeros((3, 3))
+        check(self._lib.pcp_icp_fetch_pose(self._ctx, f64p(t_opt), f64p(R_opt)))
+        return t_opt, R_opt
+
+    def poseFromSteps(self, dx_steps):
+        """(t_opt, R_opt) of a list of steps (rows of 6: t, angles) as PointcloudIcpContainer's loops extract it
+        (:84-100, :333-347), on the device."""
+        dx = np.ascontiguousarray(dx_steps, dtype=np.float32).reshape(-1, 6)
+        t_opt, R_opt = np.zeros(3), np.zeros((3, 3))
+        check(self._lib.pcp_pose_from_steps(self._ctx, f32p(dx) if len(dx) else None, len(dx), f64p(t_opt), f64p(R_opt)))
+        return t_opt, R_opt
+
     # ------------------------------------------------------------------ voxel map
     def bufferVoxelIndex(self, voxel_index):
         """:837-840"""

@@ -38,11 +38,14 @@ struct pcp_ctx {
     float *partials = nullptr, *lvl0 = nullptr, *lvl1 = nullptr;
     float *hb_trace = nullptr, *dx_trace = nullptr;   // max_iter_cap x 64 / x 6
     IcpState* state = nullptr;
+    void* pose_steps = nullptr;      // scratch of pcp_pose_from_steps (lazily allocated)
+    double* pose = nullptr;          // 16 doubles: t_opt[3], R_opt[9], rank flag, steps applied (pose kernel)
     float *tiles = nullptr, *tiles2 = nullptr;        // lazily allocated
     float4 origin = {0, 0, 0, 0};
     int n_a = 0, n_b = 0, n_scans = 0;
     int n_scans_search = 0;        // rings [n_scans_search, n_scans) repeat ring n_scans_search - 1 (padding)
     bool have_target = false, have_normals = false;
+    bool have_pose = false;        // a loop has run and left its pose in `pose`
     int run_mode = 0, run_max_iter = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipEvent_t nn_ev0 = nullptr, nn_ev1 = nullptr;   // around the kernels of the last pcp_nn (created on first use)

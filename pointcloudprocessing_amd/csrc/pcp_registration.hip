@@ -501,6 +501,18 @@ k_finish_batch(const FinishArgs* __restrict__ all, int mode, int max_iter, float
     finish_body(F, 1, mode, max_iter, tol, full_iter);
 }
 
+// uniform_optimal_icp of every pair of a batch / of one context: one block per pair.
+__global__ void __launch_bounds__(PCP_POSE_THREADS) k_pose_batch(const FinishArgs* __restrict__ all) {
+    const FinishArgs F = all[blockIdx.x];
+    pose_body(F);
+}
+
+__global__ void __launch_bounds__(PCP_POSE_THREADS) k_pose(const FinishArgs F) { pose_body(F); }
+
+__global__ void __launch_bounds__(PCP_POSE_THREADS) k_pose_steps(const float* __restrict__ dx, int n, double* __restrict__ out) {
+    pose_from_steps(dx, n, out);
+}
+
 __global__ void k_apply_pending_batch(const LsArgs* __restrict__ all) {
     const LsArgs A = all[blockIdx.y];
     if (!A.st->pending) return;
@@ -662,7 +674,7 @@ FinishArgs finish_args(const pcp_ctx* c) {
     FinishArgs F;
     memset(&F, 0, sizeof(F));
     F.partials = c->partials; F.n1 = cdiv(c->n_b, 64); F.lvl0 = c->lvl0; F.lvl1 = c->lvl1;
-    F.st = c->state; F.hb_out = c->hb_trace; F.dx_out = c->dx_trace;
+    F.st = c->state; F.hb_out = c->hb_trace; F.dx_out = c->dx_trace; F.pose = c->pose;
     return F;
 }
 
@@ -811,6 +823,7 @@ int pcp_create(int device, int max_points, int max_scans, pcp_ctx** out) {
     A((void**)&c->hb_trace, (size_t)pcp_ctx::max_iter_cap * 64 * sizeof(float));
     A((void**)&c->dx_trace, (size_t)pcp_ctx::max_iter_cap * 6 * sizeof(float));
     A((void**)&c->state, sizeof(IcpState));
+    A((void**)&c->pose, 16 * sizeof(double));
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipHostMalloc((void**)&c->scan_host, (size_t)max_scans * sizeof(int2));
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->scan_copied, hipEventDisableTiming);
@@ -837,7 +850,7 @@ int pcp_destroy(pcp_ctx* c) {
     }
     if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
     void* bufs[] = {c->a, c->ua, c->normals, c->b32, c->b_in, c->b64, c->hint, c->nn_dist, c->nn_idx, c->scan, c->ring_stat, c->ring_bins,
-                    c->partials, c->lvl0, c->lvl1, c->hb_trace, c->dx_trace, c->state, c->tiles, c->tiles2};
+                    c->partials, c->lvl0, c->lvl1, c->hb_trace, c->dx_trace, c->state, c->pose, c->pose_steps, c->tiles, c->tiles2};
     for (void* p : bufs)
         if (p) (void)hipFree(p);
     if (c->vox) pcp_voxel_state_free(c->vox);
@@ -1123,6 +1136,44 @@ int pcp_icp_launch(pcp_ctx* c, int mode, int max_iter, float tol, int full_iter)
     PCP_CHECK(hipGetLastError());
     hipLaunchKernelGGL(k_clear_pending, dim3(1), dim3(1), 0, c->stream, c->state);
     PCP_CHECK(hipGetLastError());
+    hipLaunchKernelGGL(k_pose, dim3(1), dim3(PCP_POSE_THREADS), 0, c->stream, finish_args(c));
+    PCP_CHECK(hipGetLastError());
+    c->have_pose = true;
+    return 0;
+}
+
+int pcp_pose_from_steps(pcp_ctx* c, const float* dx_steps, int n_steps, double* t_opt3, double* R_opt9) {
+    if (int e = use(c)) return e;
+    if (!t_opt3 || !R_opt9 || (n_steps > 0 && !dx_steps)) return pcp_fail("null argument");
+    if (n_steps < 0 || n_steps > pcp_ctx::max_iter_cap) return pcp_fail("n_steps = %d outside [0, %d]", n_steps, pcp_ctx::max_iter_cap);
+    if (!c->pose_steps) {
+        PCP_CHECK(hipMalloc(&c->pose_steps, (size_t)pcp_ctx::max_iter_cap * 6 * sizeof(float) + 16 * sizeof(double)));
+    }
+    double* out = reinterpret_cast<double*>(c->pose_steps);                 // 16 doubles in front, the steps behind them
+    float* steps = reinterpret_cast<float*>(out + 16);
+    if (n_steps) PCP_CHECK(hipMemcpyAsync(steps, dx_steps, (size_t)n_steps * 6 * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_pose_steps, dim3(1), dim3(PCP_POSE_THREADS), 0, c->stream, steps, n_steps, out);
+    PCP_CHECK(hipGetLastError());
+    double pose[13];
+    PCP_CHECK(hipMemcpyAsync(pose, out, sizeof(pose), hipMemcpyDeviceToHost, c->stream));
+    PCP_CHECK(hipStreamSynchronize(c->stream));
+    for (int k = 0; k < 3; ++k) t_opt3[k] = pose[k];
+    for (int k = 0; k < 9; ++k) R_opt9[k] = pose[3 + k];
+    if (pose[12] != 0.0) return pcp_fail("the tracking grid's cross-covariance is rank-deficient");
+    return 0;
+}
+
+int pcp_icp_fetch_pose(pcp_ctx* c, double* t_opt3, double* R_opt9) {
+    if (int e = use(c)) return e;
+    if (!t_opt3 || !R_opt9) return pcp_fail("null output");
+    if (!c->have_pose) return pcp_fail("no finished loop to take a pose from (pcp_icp_launch or a batch launch first)");
+    double pose[16];
+    PCP_CHECK(hipMemcpyAsync(pose, c->pose, sizeof(pose), hipMemcpyDeviceToHost, c->stream));
+    PCP_CHECK(hipStreamSynchronize(c->stream));
+    for (int k = 0; k < 3; ++k) t_opt3[k] = pose[k];
+    for (int k = 0; k < 9; ++k) R_opt9[k] = pose[3 + k];
+    if (pose[0] != pose[0]) return pcp_fail("no pose: the loop met singular normal equations");
+    if (pose[12] != 0.0) return pcp_fail("no pose: the tracking grid's cross-covariance is rank-deficient");
     return 0;
 }
 
@@ -1377,6 +1428,9 @@ int pcp_batch_icp_launch(pcp_batch* b, int mode, int max_iter, float tol, int fu
     PCP_CHECK(hipGetLastError());
     hipLaunchKernelGGL(k_state_batch, dim3(cdiv(n, 64)), dim3(64), 0, b->stream, b->ls_dev, n, 0);
     PCP_CHECK(hipGetLastError());
+    hipLaunchKernelGGL(k_pose_batch, dim3(n), dim3(PCP_POSE_THREADS), 0, b->stream, b->fin_dev);
+    PCP_CHECK(hipGetLastError());
+    for (pcp_ctx* c : b->ctxs) c->have_pose = true;
     return 0;
 }
 

@@ -235,6 +235,7 @@ __global__ void __launch_bounds__(64) k_seq_describe(const SeqDescribe D) {
 // What the host wants back per pair, gathered into one array so that a single copy fetches a whole run.
 struct SeqRecord {
     int iters, converged, singular, flags, n_a, n_b, n_lines, pad;
+    double pose[12];                 // t_opt[3], R_opt[9] (uniform_optimal_icp of the applied steps)
     float dx[PCP_SEQ_MAX_ITER * 6];
 };
 
@@ -252,6 +253,7 @@ __global__ void k_seq_results(const LsArgs* __restrict__ ls, const FinishArgs* _
         r->n_lines = (int)ring_counts[(size_t)p * ring_stride + ring_tiles]; r->pad = 0;
     }
     for (int k = threadIdx.x; k < PCP_SEQ_MAX_ITER * 6; k += blockDim.x) r->dx[k] = (k < it * 6) ? fin[p].dx_out[k] : 0.0f;
+    if (threadIdx.x < 12) r->pose[threadIdx.x] = flags[p] ? 0.0 : fin[p].pose[threadIdx.x];
 }
 
 }  // namespace
@@ -505,6 +507,7 @@ int pcp_seq_submit_placed(pcp_seq* s, const float* const* raw_xyzi, const int* n
         hipLaunchKernelGGL(k_finish_batch, dim3(P), dim3(1024), 0, q, s->fin_dev, mode, max_iter, tol, full_iter);
     }
     PCP_CHECK(hipGetLastError());
+    hipLaunchKernelGGL(k_pose_batch, dim3(P), dim3(PCP_POSE_THREADS), 0, q, s->fin_dev);       // every pair's (t_opt, R_opt)
     hipLaunchKernelGGL(k_seq_results, dim3(P), dim3(64), 0, q, s->ls_dev, s->fin_dev, s->flags_dev, s->n_pts, s->ring_counts,
                        s->stride, s->tiles, P, s->rec_dev);
     PCP_CHECK(hipGetLastError());
@@ -524,6 +527,11 @@ int pcp_seq_submit(pcp_seq* s, const float* const* raw_xyzi, const int* n_raw, i
 }
 
 int pcp_seq_collect(pcp_seq* s, int ticket, float* dx_trace, int dx_stride_iters, int* iters, int* converged, int* n_points) {
+    return pcp_seq_collect_poses(s, ticket, nullptr, nullptr, dx_trace, dx_stride_iters, iters, converged, n_points);
+}
+
+int pcp_seq_collect_poses(pcp_seq* s, int ticket, double* t_opt, double* R_opt, float* dx_trace, int dx_stride_iters, int* iters,
+                          int* converged, int* n_points) {
     if (!s) return pcp_fail("null sequence");
     const int slot = ticket & 1;
     if (ticket < 0 || !s->in_flight[slot] || s->ticket_of[slot] != ticket) return pcp_fail("ticket %d is not in flight", ticket);
@@ -547,6 +555,8 @@ int pcp_seq_collect(pcp_seq* s, int ticket, float* dx_trace, int dx_stride_iters
         if (converged) converged[p] = r.converged;
         if (n_points) { n_points[p] = r.n_a; n_points[p + 1] = r.n_b; }
         if (dx_trace) memcpy(dx_trace + (size_t)p * dx_stride_iters * 6, r.dx, (size_t)s->iters[slot] * 6 * sizeof(float));
+        if (t_opt) memcpy(t_opt + 3 * (size_t)p, r.pose, 3 * sizeof(double));
+        if (R_opt) memcpy(R_opt + 9 * (size_t)p, r.pose + 3, 9 * sizeof(double));
         if ((r.flags || r.singular) && bad < 0) bad = p;
     }
     if (bad >= 0) {

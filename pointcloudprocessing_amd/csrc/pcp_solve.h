@@ -126,6 +126,163 @@ __device__ __forceinline__ void pose_step(const float (&v)[PCP_NVAL], IcpState* 
     if (it + 1 >= max_iter) st->done = 1;
 }
 
+// U V^T of the singular value decomposition W = U S V^T of a 3x3 matrix (row-major), what
+// uniform_optimal_icp (PointcloudIcpContainer.py:342-344) forms from np.linalg.svd -- without a
+// determinant fix, as there.  One-sided Jacobi: the columns of A = W V are made orthogonal by plane
+// rotations collected in V; their lengths are the singular values and U = A / S.  For a W of full rank
+// U V^T is its orthogonal polar factor and does not depend on how the decomposition orders or signs the
+// singular triplets.  A column of zero length (rank-deficient W, where LAPACK's choice of U is arbitrary)
+// is replaced by the cross product of the other two, and `deficient` is set.
+__device__ inline void polar_uvt3(const double* W, double* R, int* deficient) {
+    double A[3][3], V[3][3];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) { A[i][j] = W[i * 3 + j]; V[i][j] = (i == j) ? 1.0 : 0.0; }
+    for (int sweep = 0; sweep < 40; ++sweep) {
+        bool rotated = false;
+        for (int p = 0; p < 2; ++p)
+            for (int q = p + 1; q < 3; ++q) {
+                double alpha = 0.0, beta = 0.0, gamma = 0.0;
+                for (int k = 0; k < 3; ++k) { alpha += A[k][p] * A[k][p]; beta += A[k][q] * A[k][q]; gamma += A[k][p] * A[k][q]; }
+                if (gamma == 0.0 || fabs(gamma) <= 2.3e-16 * sqrt(alpha * beta)) continue;
+                rotated = true;
+                const double zeta = (beta - alpha) / (2.0 * gamma);
+                const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                const double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
+                for (int k = 0; k < 3; ++k) {
+                    const double ap = A[k][p], aq = A[k][q];
+                    A[k][p] = c * ap - s * aq; A[k][q] = s * ap + c * aq;
+                    const double vp = V[k][p], vq = V[k][q];
+                    V[k][p] = c * vp - s * vq; V[k][q] = s * vp + c * vq;
+                }
+            }
+        if (!rotated) break;
+    }
+    double sig[3], big = 0.0;
+    for (int j = 0; j < 3; ++j) {
+        sig[j] = sqrt((A[0][j] * A[0][j] + A[1][j] * A[1][j]) + A[2][j] * A[2][j]);
+        big = sig[j] > big ? sig[j] : big;
+    }
+    int bad = 0;
+    for (int j = 0; j < 3; ++j) {
+        if (sig[j] > 1e-300 && sig[j] > 1e-14 * big) { for (int k = 0; k < 3; ++k) A[k][j] /= sig[j]; }
+        else bad |= 1 << j;
+    }
+    if (bad) {
+        for (int j = 0; j < 3; ++j) {
+            if (!(bad & (1 << j))) continue;
+            const int a = (j + 1) % 3, b = (j + 2) % 3;
+            if ((bad & (1 << a)) || (bad & (1 << b))) {       // fewer than two directions left: any orthonormal completion
+                for (int k = 0; k < 3; ++k) A[k][j] = (k == j) ? 1.0 : 0.0;
+                continue;
+            }
+            A[0][j] = A[1][a] * A[2][b] - A[2][a] * A[1][b];
+            A[1][j] = A[2][a] * A[0][b] - A[0][a] * A[2][b];
+            A[2][j] = A[0][a] * A[1][b] - A[1][a] * A[0][b];
+        }
+    }
+    if (deficient) *deficient = bad ? 1 : 0;
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j)
+            R[i * 3 + j] = (A[i][0] * V[j][0] + A[i][1] * V[j][1]) + A[i][2] * V[j][2];
+}
+
+// Coordinate k (0..9) of np.linspace(-1, 1, 10): arange * step + start with step = 2 / 9, the end point set to stop
+// (PointcloudIcpContainer.getUniformGrid :429-438).
+__device__ __forceinline__ double grid_axis10(const int k) {
+    if (k == 9) return 1.0;
+    const double step = 2.0 / 9.0;
+    const double v = (double)k * step;
+    return v + (-1.0);
+}
+
+// The pose a registration returns (full_pt2pt :84-100, full_pt2pl :118-140): the 10x10x10 tracking grid on
+// [-1, 1]^3 is moved by every applied step, g <- R g + t (applyIcpStep :320-322, float64, left to right), and
+// uniform_optimal_icp (:333-347) reads the pose off it: means, W = (g' - mean')^T (g - mean), R_opt = U V^T,
+// t_opt = mean' - R_opt mean.  One block of PCP_POSE_THREADS threads; thread 0 leaves t_opt in out[0..3), R_opt (row-major)
+// in out[3..12), out[12] = 1 when W was rank-deficient.  `applied` steps of 6 float32 (t, then the angles) are read from dx.
+#define PCP_POSE_THREADS 256
+__device__ inline void pose_from_steps(const float* __restrict__ dx, const int applied, double* __restrict__ out) {
+    __shared__ double s_red[PCP_POSE_THREADS / 64][12];
+    __shared__ double s_mean[6];
+    __shared__ double s_Rt[12];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int PER = (1000 + PCP_POSE_THREADS - 1) / PCP_POSE_THREADS;
+    double g0[PER][3], g[PER][3];
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const int i = tid + j * PCP_POSE_THREADS;
+        const int ii = i < 1000 ? i : 0;
+        g0[j][0] = grid_axis10(ii / 100); g0[j][1] = grid_axis10((ii / 10) % 10); g0[j][2] = grid_axis10(ii % 10);
+        g[j][0] = g0[j][0]; g[j][1] = g0[j][1]; g[j][2] = g0[j][2];
+    }
+    for (int s = 0; s < applied; ++s) {
+        __syncthreads();
+        if (tid == 0) {
+            const float* d = dx + (size_t)s * 6;
+            rotation_xyz(d[3], d[4], d[5], s_Rt);
+            s_Rt[9] = (double)d[0]; s_Rt[10] = (double)d[1]; s_Rt[11] = (double)d[2];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            const double x = g[j][0], y = g[j][1], z = g[j][2];
+            g[j][0] = ((s_Rt[0] * x + s_Rt[1] * y) + s_Rt[2] * z) + s_Rt[9];
+            g[j][1] = ((s_Rt[3] * x + s_Rt[4] * y) + s_Rt[5] * z) + s_Rt[10];
+            g[j][2] = ((s_Rt[6] * x + s_Rt[7] * y) + s_Rt[8] * z) + s_Rt[11];
+        }
+    }
+    // block sums in a fixed order: a thread's own points, the wave's butterfly, the waves one after the other
+    auto block_sum = [&](double (&v)[12], const int n) {
+        for (int k = 0; k < n; ++k)
+            for (int sft = 32; sft > 0; sft >>= 1) v[k] += __shfl_down(v[k], sft, 64);
+        __syncthreads();
+        if (lane == 0) for (int k = 0; k < n; ++k) s_red[wave][k] = v[k];
+        __syncthreads();
+    };
+    double v[12];
+    for (int k = 0; k < 12; ++k) v[k] = 0.0;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        if (tid + j * PCP_POSE_THREADS < 1000) {
+            for (int k = 0; k < 3; ++k) { v[k] += g[j][k]; v[3 + k] += g0[j][k]; }
+        }
+    }
+    block_sum(v, 6);
+    if (tid == 0)
+        for (int k = 0; k < 6; ++k) {
+            double sum = 0.0;
+            for (int w = 0; w < PCP_POSE_THREADS / 64; ++w) sum += s_red[w][k];
+            s_mean[k] = sum / 1000.0;
+        }
+    __syncthreads();
+    for (int k = 0; k < 12; ++k) v[k] = 0.0;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        if (tid + j * PCP_POSE_THREADS < 1000) {
+            const double a[3] = {g[j][0] - s_mean[0], g[j][1] - s_mean[1], g[j][2] - s_mean[2]};
+            const double b[3] = {g0[j][0] - s_mean[3], g0[j][1] - s_mean[4], g0[j][2] - s_mean[5]};
+            for (int r = 0; r < 3; ++r)
+                for (int c = 0; c < 3; ++c) v[r * 3 + c] += a[r] * b[c];
+        }
+    }
+    block_sum(v, 9);
+    if (tid == 0) {
+        double W[9], R[9];
+        for (int k = 0; k < 9; ++k) {
+            double sum = 0.0;
+            for (int w = 0; w < PCP_POSE_THREADS / 64; ++w) sum += s_red[w][k];
+            W[k] = sum;
+        }
+        int deficient = 0;
+        polar_uvt3(W, R, &deficient);
+        for (int r = 0; r < 3; ++r)
+            out[r] = s_mean[r] - ((R[r * 3 + 0] * s_mean[3] + R[r * 3 + 1] * s_mean[4]) + R[r * 3 + 2] * s_mean[5]);
+        for (int k = 0; k < 9; ++k) out[3 + k] = R[k];
+        out[12] = deficient ? 1.0 : 0.0;
+    }
+    __syncthreads();
+}
+
 // Upper levels of the ParalellHBSum tree (ComputeShader.py:682-707) over the
 // level-1 partials, then -- when solve != 0 -- the host half of one iteration:
 // dispatchPointToPoint / dispatchPointToPlane (PointcloudIcpContainer.py:24-29,
@@ -133,7 +290,23 @@ __device__ __forceinline__ void pose_step(const float (&v)[PCP_NVAL], IcpState* 
 struct FinishArgs {
     const float* partials; int n1; float* lvl0; float* lvl1;
     IcpState* st; float* hb_out; float* dx_out;
+    double* pose;        // 16 doubles: t_opt[3], R_opt[9], rank flag, steps applied, 2 unused (written by the pose kernel)
 };
+
+// The pose of a finished loop from its recorded steps (see pose_from_steps).  A converged point-to-plane loop did not
+// apply its last step (PointcloudIcpContainer.py:121-122: break before apply); a singular system leaves NaN.
+__device__ inline void pose_body(const FinishArgs& F) {
+    const IcpState* st = F.st;
+    const int iters = st->iter, singular = st->singular;
+    int applied = iters - (st->converged ? 1 : 0);
+    if (singular) applied = iters - 1;
+    if (applied < 0) applied = 0;
+    pose_from_steps(F.dx_out, applied, F.pose);
+    if (threadIdx.x == 0) {
+        F.pose[13] = (double)applied;
+        if (singular) { const double nan = __longlong_as_double(0x7ff8000000000000ll); for (int k = 0; k < 12; ++k) F.pose[k] = nan; }
+    }
+}
 
 __device__ __forceinline__ void finish_body(const FinishArgs& F, const int solve, const int mode, const int max_iter,
                                             const float tol, const int full_iter) {

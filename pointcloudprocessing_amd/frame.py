@@ -107,7 +107,6 @@ class DeviceFrame:
 def register_frames(compute, target, source, origin, point_to_plane=True, iterations=10, tol=1e-6, full_iter=False):
     """full_pt2pl / full_pt2pt (PointcloudIcpContainer.py:71-144) between two DeviceFrames: returns
     (t_opt, R_opt), dx trace and the convergence flag; the source frame itself is not modified."""
-    from .icp_container import PointcloudIcpContainer
     lib = compute._lib
     lines = target.scan_lines(origin)
     target.as_target(compute, lines, origin, point_to_plane)
@@ -119,6 +118,5 @@ def register_frames(compute, target, source, origin, point_to_plane=True, iterat
     check(lib.pcp_icp_fetch(compute._ctx, f32p(dx), None, C.byref(it), C.byref(cv), None))
     dx = dx[:it.value]
     conv = bool(cv.value)
-    applied = len(dx) - 1 if (conv and point_to_plane and not full_iter) else len(dx)
-    t_opt, R_opt = PointcloudIcpContainer(compute)._replay(dx, applied)
+    t_opt, R_opt = compute.fetchPose()
     return (t_opt, R_opt), dx, conv

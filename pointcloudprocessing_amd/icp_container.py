@@ -121,6 +121,13 @@ class PointcloudIcpContainer:
         R_opt, t_opt = self.uniform_optimal_icp(grid, self.getUniformGrid(10))
         return t_opt, R_opt
 
+    def _pose(self, dx_trace, applied):
+        """(t_opt, R_opt) of the loop that just ran: the device's (ComputeShader.fetchPose: the tracking grid is
+        replayed and the Kabsch extraction done behind the loop); the host replay for compute objects without it."""
+        if hasattr(self.compute, "fetchPose"):
+            return self.compute.fetchPose()
+        return self._replay(dx_trace, applied)
+
     def _keep(self, aligned, origin, mode):
         self._kept = (aligned, np.array(origin, dtype=np.float64), mode, getattr(self.compute, "target_serial", None))
 
@@ -143,7 +150,7 @@ class PointcloudIcpContainer:
         if renderer is not None:
             return self._full_stepwise(to_align, iterations, renderer, plane=False, full_iter=True)
         dx, _, _, _ = self.compute.icpRun(to_align, MODE_POINT, iterations)
-        return self._replay(dx, len(dx))
+        return self._pose(dx, len(dx))
 
     def full_pt2pl(self, aligned, to_align, origin, iterations=20, renderer=None, full_iter=False):
         """:103-144 -> (t_opt, R_opt); stops when mean|dx| < 1e-6 unless full_iter."""
@@ -153,7 +160,7 @@ class PointcloudIcpContainer:
         if renderer is not None:
             return self._full_stepwise(to_align, iterations, renderer, plane=True, full_iter=full_iter)
         dx, converged, _, _ = self.compute.icpRun(to_align, MODE_PLANE, iterations, tol=1e-6, full_iter=full_iter)
-        return self._replay(dx, len(dx) - 1 if converged else len(dx))
+        return self._pose(dx, len(dx) - 1 if converged else len(dx))
 
     def _full_stepwise(self, to_align, iterations, renderer, plane, full_iter):
         """The reference's host loop, one dispatch per iteration, for callers

@@ -52,7 +52,7 @@ def register_pairs(targets, sources, origin=None, point_to_plane=True, iteration
                 results = [computes[s].icpRun(moved[s], mode, iterations)[:2] + (None, None) for s in range(len(idx))]
             for slot, k in enumerate(idx):
                 dx, converged = results[slot][0], results[slot][1]
-                t, R = icps[slot]._replay(dx, len(dx) - 1 if (converged and point_to_plane) else len(dx))
+                t, R = computes[slot].fetchPose()          # tracking grid + Kabsch behind the loop, on the device
                 if guesses is not None and guesses[k] is not None:
                     t0, R0 = guesses[k]                      # p <- R (R0 p - t0) - t
                     t, R = R @ t0 + t, R @ R0

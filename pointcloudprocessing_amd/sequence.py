@@ -98,18 +98,28 @@ class SequencePipeline:
     def collect(self, ticket):
         """-> (steps, n_points): steps[p] = (dx trace (iters, 6) float32, converged) of pair p = (frame p <- frame p + 1),
         n_points[f] = points frame f kept after the ego filter."""
+        steps, n_pts, _ = self.collect_with_poses(ticket)
+        return steps, n_pts
+
+    def collect_with_poses(self, ticket):
+        """collect() plus every pair's (t_opt, R_opt) as full_pt2pl / full_pt2pt return them (PointcloudIcpContainer.py:140,
+        :333-347: p <- R_opt p - t_opt maps frame p + 1 into frame p), computed on the device behind the loops (tracking
+        grid + Kabsch, pcp_seq_collect_poses) and fetched in the same copy as the steps."""
         frames, n_frames, iterations, plane, full_iter = self._runs.pop(ticket)
         P = n_frames - 1
         dx = np.zeros((P, iterations, 6), dtype=np.float32)
         iters = np.zeros(P, dtype=np.int32)
         conv = np.zeros(P, dtype=np.int32)
         n_pts = np.zeros(n_frames, dtype=np.int32)
-        check(self._lib.pcp_seq_collect(self._seq, int(ticket), f32p(dx), iterations, i32p(iters), i32p(conv), i32p(n_pts)))
-        return [(dx[p, :iters[p]].copy(), bool(conv[p])) for p in range(P)], n_pts
+        t_opt, R_opt = np.zeros((P, 3)), np.zeros((P, 3, 3))
+        check(self._lib.pcp_seq_collect_poses(self._seq, int(ticket), f64p(t_opt), f64p(R_opt), f32p(dx), iterations,
+                                              i32p(iters), i32p(conv), i32p(n_pts)))
+        return ([(dx[p, :iters[p]].copy(), bool(conv[p])) for p in range(P)], n_pts,
+                [(t_opt[p], R_opt[p]) for p in range(P)])
 
     def poses(self, steps, point_to_plane=True, full_iter=False):
-        """(t_opt, R_opt) per pair from its steps, as full_pt2pl / full_pt2pt return them
-        (PointcloudIcpContainer.py:140, :333-347): p <- R_opt p - t_opt maps frame p + 1 into frame p."""
+        """The same poses recomputed on the host from the steps (NumPy replay of the tracking grid + SVD, as the
+        reference does it); collect_with_poses returns the device's."""
         out = []
         for dx, conv in steps:
             applied = len(dx) - 1 if (conv and point_to_plane and not full_iter) else len(dx)
@@ -161,10 +171,10 @@ def sequence_odometry_raw(raw_frames, point_to_plane=True, iterations=10, rank=0
                                                 iterations=iterations)))
                 if len(pending) == 2:
                     b0, t = pending.pop(0)
-                    for j, pose in enumerate(pipe.poses(pipe.collect(t)[0], point_to_plane)):
+                    for j, pose in enumerate(pipe.collect_with_poses(t)[2]):
                         local[lo + b0 + j] = pose
             for b0, t in pending:
-                for j, pose in enumerate(pipe.poses(pipe.collect(t)[0], point_to_plane)):
+                for j, pose in enumerate(pipe.collect_with_poses(t)[2]):
                     local[lo + b0 + j] = pose
         finally:
             pipe.close()
@@ -213,7 +223,7 @@ def sequence_odometry_imu(raw_frames, records, point_to_plane=True, iterations=1
             pending = []
 
             def take(b0, ticket):
-                for j, pose in enumerate(pipe.poses(pipe.collect(ticket)[0], point_to_plane)):
+                for j, pose in enumerate(pipe.collect_with_poses(ticket)[2]):
                     local[lo + b0 + j] = pose
 
             for c0 in range(0, hi - lo, chunk):

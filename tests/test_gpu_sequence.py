@@ -107,6 +107,40 @@ def _raw4(raw3):
     return np.ascontiguousarray(np.column_stack([raw3, np.zeros(len(raw3), np.float32)]), dtype=np.float32)
 
 
+def _oracle_replay(dx, applied):
+    """(t_opt, R_opt) of a step trace by the restatement: grid <- R grid + t per applied step, then Kabsch."""
+    grid = O.uniform_grid(10)
+    for d in dx[:applied]:
+        grid = O.apply_icp_step(grid, O.rotation(d[3], d[4], d[5]), d[:3])
+    R_opt, t_opt = O.uniform_optimal_icp(grid, O.uniform_grid(10))
+    return t_opt, R_opt
+
+
+def test_device_pose_extraction_against_the_reference_known_answer():
+    """uniform_optimal_icp of the reference itself (ref_kat: one step applied to the 10^3 grid, then its Kabsch
+    extraction, PointcloudIcpContainer.py:333-347) against the device's extraction of the same step; random step
+    lists against the restatement's replay; no step = identity."""
+    K = golden("ref_kat.npz")
+    cs = ComputeShader(maxPointsPerCloud=1000, maxScans=4)
+    try:
+        step = np.concatenate([K["alg_t"], K["rot_angles"][1]]).astype(np.float32)
+        t_opt, R_opt = cs.poseFromSteps([step])
+        # the reference's rotation() took NumPy's float32 cosines; the device rounds float64 ones (an ulp apart at most)
+        assert np.abs(R_opt - K["alg_Ropt"]).max() < 2.5e-7 and np.abs(t_opt - K["alg_topt"]).max() < 2.5e-7
+        t_o, R_o = _oracle_replay(step[None, :], 1)
+        assert np.abs(R_opt - R_o).max() < 1e-13 and np.abs(t_opt - t_o).max() < 1e-13
+        t_opt, R_opt = cs.poseFromSteps(np.zeros((0, 6), np.float32))
+        assert np.abs(R_opt - np.eye(3)).max() < 1e-15 and np.abs(t_opt).max() < 1e-15
+        rng = np.random.default_rng(5)
+        for n in (1, 2, 7, 20, 32):
+            steps = np.concatenate([rng.uniform(-0.4, 0.4, (n, 3)), rng.uniform(-0.2, 0.2, (n, 3))], axis=1).astype(np.float32)
+            t_opt, R_opt = cs.poseFromSteps(steps)
+            t_o, R_o = _oracle_replay(steps, n)
+            assert np.abs(R_opt - R_o).max() < 1e-12 and np.abs(t_opt - t_o).max() < 1e-11, n
+    finally:
+        cs.cleanup()
+
+
 @pytest.mark.parametrize("plane,iterations", [(True, 10), (False, 6)])
 def test_pipeline_equals_the_pair_by_pair_device_path(plane, iterations):
     """Raw bytes in, steps out: every pair's dx trace, convergence flag and point counts equal those of
@@ -125,11 +159,18 @@ def test_pipeline_equals_the_pair_by_pair_device_path(plane, iterations):
         with pytest.raises(Exception, match="in flight"):
             pipe.submit(pinned, point_to_plane=plane, iterations=iterations)
         short, n_short = pipe.collect(t_short)
-        steps, n_pts = pipe.collect(t_all)
+        steps, n_pts, poses = pipe.collect_with_poses(t_all)
         assert len(short) == 4 and len(steps) == N_FRAMES - 1
         for p in range(4):
             assert np.array_equal(bits(short[p][0]), bits(steps[p][0])) and short[p][1] == steps[p][1]
-        poses = pipe.poses(steps, plane)
+        # the poses come from the device (tracking grid + Kabsch behind the loops): equal to the restatement's replay of
+        # the same steps to rounding, and to the NumPy replay of the reference's own functions (whose float32 cosines
+        # may differ by an ulp) far inside the 1e-5 / 1e-4 the poses have to meet
+        for (t_dev, R_dev), (t_np, R_np), (dx, conv) in zip(poses, pipe.poses(steps, plane), steps):
+            t_o, R_o = _oracle_replay(dx, len(dx) - 1 if (conv and plane) else len(dx))
+            assert np.abs(R_dev - R_o).max() < 1e-12 and np.abs(t_dev - t_o).max() < 1e-12
+            assert np.abs(R_dev - R_np).max() < 1e-6 and np.abs(t_dev - t_np).max() < 1e-6
+            assert abs(np.linalg.det(R_dev) - 1.0) < 1e-12 and np.abs(R_dev @ R_dev.T - np.eye(3)).max() < 1e-14
         for p in range(N_FRAMES - 1):
             assert fa.decode(raws[p]) == n_pts[p] and fb.decode(raws[p + 1]) == n_pts[p + 1]
             (t_opt, R_opt), dx, conv = register_frames(cs, fa, fb, np.zeros(3), point_to_plane=plane, iterations=iterations)
@@ -229,9 +270,8 @@ def test_pipeline_with_imu_placements_equals_the_host_driven_pairs():
     cs = ComputeShader(maxPointsPerCloud=131072, maxScans=100)
     icp = PointcloudIcpContainer(cs)
     try:
-        steps, n_pts = pipe.collect(pipe.submit(pinned, point_to_plane=True, iterations=10, placements=place))
+        steps, n_pts, poses = pipe.collect_with_poses(pipe.submit(pinned, point_to_plane=True, iterations=10, placements=place))
         plain, _ = pipe.collect(pipe.submit(pinned, point_to_plane=True, iterations=10))
-        poses = pipe.poses(steps, True)
         first_steps, first_plain = [], []
         for p in range(N_FRAMES - 1):
             target = (place[p][0] @ frames[p].T).T
@@ -342,7 +382,11 @@ def test_two_ranks_share_a_run_of_frames(tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     script = tmp_path / "worker.py"
     script.write_text(ODO_WORKER)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29631", WORLD_SIZE="2")
+    import socket
+    with socket.socket() as sk:           # a rendezvous port nobody holds
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE="2")
     procs = [subprocess.Popen([sys.executable, str(script), root, str(tmp_path)], env=dict(env, RANK=str(r))) for r in range(2)]
     try:
         for p in procs:
