@@ -133,26 +133,27 @@ def run_sequence(args, rank, world, device, barrier):
         raise SystemExit("--workload sequence-imu needs the KITTI fixtures and their OXTS records")
 
     def run(steps):
+        # every collect fetches the pairs' steps AND their poses (t_opt, R_opt: tracking grid + Kabsch on the device,
+        # one record array per run): the poses are on the host when the clock stops
         last, pending = None, None
         for _ in range(steps):
             t = pipe.submit(frames, point_to_plane=True, iterations=MAX_ITER, tol=TOL, placements=main_placements)
             if pending is not None:
-                last = pipe.collect(pending)
+                last = pipe.collect_with_poses(pending)
             pending = t
         if pending is not None:
-            last = pipe.collect(pending)
+            last = pipe.collect_with_poses(pending)
         return last
 
     run(args.warmup)
     barrier()
     t0 = time.perf_counter()
-    steps, n_pts = run(args.steps)
+    steps, n_pts, poses = run(args.steps)
     barrier()
     elapsed = time.perf_counter() - t0
 
-    # what the timed steps computed, and a sanity check on it: a pair and the same pair walked backwards
+    # a sanity check on the poses the timed steps delivered: a pair and the same pair walked backwards
     # must be inverse motions, and the car moves a few decimetres per sweep
-    poses = pipe.poses(steps, True)
     seen = {}
     for p, (t, R) in enumerate(poses):
         seen[(order[p], order[p + 1])] = (t, R)
@@ -225,7 +226,8 @@ def run_sequence(args, rank, world, device, barrier):
         "data": "real sweeps: " + source, "n_a": int(np.mean(n_pts[:-1])), "n_b": n_b, "iters": float(np.mean(iters)),
         "workload": "configs[3] on one GPU's share (the config the metric is quoted on): frame-to-frame point-to-plane ICP "
                     "with ring normals over consecutive real KITTI sweeps, <= 10 iterations, from raw bytes in host memory "
-                    "(upload, decode, ring segmentation, normals, loop, fetch all inside the clock)"
+                    "to every pair's pose (t_opt, R_opt) on the host (upload, decode, ring segmentation, normals, loop, "
+                    "tracking grid + Kabsch, fetch all inside the clock)"
                     + ("; every frame placed by its OXTS record first (IMU rotation, dead-reckoned offset of the source)"
                        if main_placements else ""),
         "kernel": "k_ls_batch<plane> (fused ring-NN + JtJ/Jte + level-1 tree sum, all pairs of the step in one launch)",

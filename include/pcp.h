@@ -240,6 +240,55 @@ int pcp_voxel_store_enable(pcp_ctx* ctx, int on);
  * the next call of this function; the call returns when it is complete.  n_rows (or NULL) receives the rows staged. */
 int pcp_voxel_staged_points(pcp_ctx* ctx, const double** xyz_dev, size_t* n_points, int* n_rows);
 
+/* ---- a whole frame of Voxelizer.addPoints (Voxelizer.py:81-133) as one enqueue and one wait -----------------
+ * What the reference does per frame in five round trips -- handleAddingPoints' float32 cast (:398-425), the
+ * dispatch of VoxelShader.glsl (ComputeShader.prepareDispatchVoxelizer :847-944), the stager dispatch
+ * (prepareDispatchVoxelStager :761-835, per-frame mode: stage_everything = False), the creation of the new voxels
+ * (storeUnknownPoints :170-306) -- runs here as one stream of kernels on the device-resident map (pcp_voxel_reserve
+ * / pcp_voxel_insert_unknown): every count the host used to read between the steps (unknown points, new voxels,
+ * stored voxels, staged rows) stays in device memory, launches are sized for capacities the host can bound, and
+ * capacity is reserved ahead of need, so the call only enqueues.  Results equal the step-by-step calls: table,
+ * data rows (count of all points, the first max_points - 1 ids ascending), statistics, staged rows.
+ *   layout   PCP_PTS_F64_XYZ: n rows of 3 float64 (cast to float32 as handleAddingPoints does);
+ *            PCP_PTS_F32_XYZW / _XYZ / _ROWS: float32 rows of 4, rows of 3, or three coordinate rows of n
+ *   stored   voxels in the table as the caller knows them after a step-by-step call, or -1: as the device knows them
+ *            from the frames fed before (required after any step-by-step call that changes the table)
+ *   serial   ticket for pcp_voxel_add_wait; at most 8 frames may be un-waited (the 9th call waits for the oldest)
+ * pcp_voxel_add takes host memory (copied on the context's stream; the buffer must stay valid until the wait),
+ * pcp_voxel_add_dev device memory produced on `after_stream` (NULL: already complete or on the context's stream).
+ * The statistics are the resident ones of pcp_voxel_stage_resident.  A frame whose unknown points span more than
+ * 2^16 voxels along an axis is refused at the wait (map unchanged by its unknown points). */
+#define PCP_PTS_F32_XYZW 4
+#define PCP_PTS_F32_XYZ 3
+#define PCP_PTS_F32_ROWS (-3)
+#define PCP_PTS_F64_XYZ 8
+typedef struct pcp_voxel_frame {
+    int serial;          /* ticket */
+    int stored_before;   /* voxels in the table when the frame arrived */
+    int stored;          /* voxels in the table now */
+    int unknown;         /* points whose voxel did not exist (unknown_point_inds[0]) */
+    int created;         /* voxels created */
+    int staged;          /* rows the stager released (counter_buffer[0][0]) */
+    int key_bits;        /* bits of the voxel keys the creation sorted by */
+    int flags;           /* bit 0: key range too wide, bit 1: a new voxel already existed, bit 2: coordinate beyond +-2^20 */
+} pcp_voxel_frame;
+int pcp_voxel_add(pcp_ctx* ctx, const void* pts_host, int layout, int n, float voxel_size, int stored, int begin_index,
+                  int max_points, int filter_outliers, int max_staging, int* serial);
+int pcp_voxel_add_dev(pcp_ctx* ctx, const void* pts_dev, int layout, int n, float voxel_size, int stored, int begin_index,
+                      int max_points, int filter_outliers, int max_staging, void* after_stream, int* serial);
+/* Waits for frame `serial` (and every frame before it) and returns its record; fails when the frame was refused. */
+int pcp_voxel_add_wait(pcp_ctx* ctx, int serial, pcp_voxel_frame* out);
+/* The unknown points of the last frame fed, on request (the reference returns them from every dispatch, :930-933):
+ * ids[0 .. unknown) grouped by voxel in the table's order, ascending inside a voxel; ids == NULL returns the count
+ * alone.  Waits. */
+int pcp_voxel_add_unknown_read(pcp_ctx* ctx, int32_t* ids, int capacity, int* count);
+/* The rows the last stager dispatch (either kind) released: rows x max_points ints, as prepareDispatchVoxelStager
+ * returns them (:823-835).  Waits. */
+int pcp_voxel_staged_read(pcp_ctx* ctx, int rows, int max_points, int32_t* stage_out);
+/* Points [first, first + n) of the device point store (pcp_voxel_store_enable) as float32 rows of 4: what
+ * Voxelizer.added_points holds for them (Voxelizer.py:398-425).  Waits. */
+int pcp_voxel_store_read(pcp_ctx* ctx, long long first, int n, float* xyzw);
+
 /* ---- batches of independent frame pairs -----------------------------------
  * Consecutive frame pairs of a sequence are independent registrations
  * (EnvironmentConstructor.py:116-132 calls full_pt2pl once per frame).  A batch

@@ -18,6 +18,11 @@ class PcpError(RuntimeError):
     pass
 
 
+class VoxelFrame(C.Structure):
+    """pcp_voxel_frame of include/pcp.h: what one fed frame did to the voxel map."""
+    _fields_ = [(n, C.c_int) for n in ("serial", "stored_before", "stored", "unknown", "created", "staged", "key_bits", "flags")]
+
+
 def _ptr(arr, ctype):
     return arr.ctypes.data_as(C.POINTER(ctype))
 
@@ -120,6 +125,13 @@ SIGNATURES = {
     "pcp_frame_points_dev": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
     "pcp_frame_padded_dev": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
     "pcp_voxel_insert_unknown": (C.c_int, [_ctx, C.c_int, _i32p, _i32p]),
+    "pcp_voxel_add": (C.c_int, [_ctx, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _i32p]),
+    "pcp_voxel_add_dev": (C.c_int, [_ctx, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                    C.c_void_p, _i32p]),
+    "pcp_voxel_add_wait": (C.c_int, [_ctx, C.c_int, C.c_void_p]),
+    "pcp_voxel_add_unknown_read": (C.c_int, [_ctx, _i32p, C.c_int, _i32p]),
+    "pcp_voxel_staged_read": (C.c_int, [_ctx, C.c_int, C.c_int, _i32p]),
+    "pcp_voxel_store_read": (C.c_int, [_ctx, C.c_longlong, C.c_int, _f32p]),
     "pcp_voxel_reset": (C.c_int, [_ctx]),
     "pcp_voxel_reserve": (C.c_int, [_ctx, C.c_int, C.c_int]),
     "pcp_voxel_index_read": (C.c_int, [_ctx, C.c_int, _i32p]),

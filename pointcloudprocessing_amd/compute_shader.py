@@ -46,6 +46,8 @@ class ComputeShader:
         self._frame = None           # device frame of prepareTargetOnDevice, made on first use
         self._n_source = None        # points of the float64 source IcpBatch.upload_sources sent last
         self._voxel_resident = None  # voxel count of a map whose device copy is the authority, else None
+        self._feed_clean = False     # the last voxel call was a fed frame: the device's own voxel count is current
+        self._feed_keep = None
         self.resident_statistics = False  # the stager's statistics stay on the device between dispatches
         self.reallocate_out(np.array([maxPointsPerCloud, maxPointsPerCloud, 0, 0]))
 
@@ -258,6 +260,8 @@ class ComputeShader:
     # ------------------------------------------------------------------ voxel map
     def bufferVoxelIndex(self, voxel_index):
         """:837-840"""
+        self._hand_over_voxel_map(None)
+        self._feed_clean = False
         vi = np.ascontiguousarray(voxel_index, dtype=np.int32)
         check(self._lib.pcp_voxel_index_upload(self._ctx, i32p(vi), len(vi)))
         self._voxel_resident = None           # the host copy is the authority again
@@ -265,23 +269,107 @@ class ComputeShader:
 
     def fullBufferVoxelData(self, voxel_data):
         """:842-845"""
+        self._feed_clean = False
         vd = np.ascontiguousarray(voxel_data, dtype=np.int32)
         check(self._lib.pcp_voxel_data_upload(self._ctx, i32p(vd), vd.shape[0], vd.shape[1]))
         self._voxel_resident = None
 
     # -- voxel map kept on the device (no counterpart in the reference, whose host recreates and
     #    re-uploads table and rows every frame)
-    def voxelReserve(self, rows, max_points):
+    def _hand_over_voxel_map(self, new_owner=None):
+        """The device's voxel map is about to be replaced: the Voxelizer whose mirrors of it are fetched on demand
+        fetches what it has not looked at yet while it still can."""
+        import weakref
+        ref = getattr(self, "_voxel_owner", None)
+        old = ref() if ref is not None else None
+        if old is not None and old is not new_owner and hasattr(old, "_detach_from_device"):
+            old._detach_from_device()
+        self._voxel_owner = weakref.ref(new_owner) if new_owner is not None else None
+
+    def voxelReserve(self, rows, max_points, owner=None):
         """Fresh, empty device table / data of `rows` rows; the device copy becomes the authority."""
+        self._hand_over_voxel_map(owner)
+        self._feed_clean = False
         check(self._lib.pcp_voxel_reset(self._ctx))
         check(self._lib.pcp_voxel_reserve(self._ctx, int(rows), int(max_points)))
         self._voxel_resident = 0
         self.voxel_map_epoch = getattr(self, "voxel_map_epoch", 0) + 1      # a new map: mirrors of the old one are void
         self.resident_statistics = False        # a Voxelizer that reads its statistics lazily switches this on
 
+    # -- a whole frame of Voxelizer.addPoints as one enqueue and one wait (pcp_voxel_add*)
+    PTS_F32_XYZW, PTS_F32_XYZ, PTS_F32_ROWS, PTS_F64_XYZ = 4, 3, -3, 8
+
+    def voxelAddFrame(self, points, voxel_size, stored_voxel_num, begin_index, max_points, filter_outliers,
+                      max_staging=1024, device_ptr=None, n_points=None, layout=None, after_stream=None):
+        """Enqueues dispatch + stager + creation of the new voxels for one cloud on the device-resident map and returns
+        a ticket for voxelAddWait.  points: a host array -- float32 (n, 4), (n, 3) or a transposed (3, n).T view,
+        float64 (n, 3) -- that must stay alive until the wait; or device_ptr / n_points / layout for a cloud already
+        in device memory (after_stream: the hipStream_t that produces it).  stored_voxel_num = -1: the device's own
+        count (allowed after a frame fed before, with no step-by-step voxel call in between)."""
+        serial = C.c_int(-1)
+        size = float(np.asarray(voxel_size).reshape(-1)[0])
+        stored = -1 if (stored_voxel_num is None or self._feed_clean) else int(stored_voxel_num)
+        if device_ptr is not None:
+            check(self._lib.pcp_voxel_add_dev(self._ctx, C.c_void_p(int(device_ptr)), int(layout), int(n_points), size, stored,
+                                              int(begin_index), int(max_points), int(bool(filter_outliers)), int(max_staging),
+                                              None if after_stream is None else C.c_void_p(int(after_stream)), C.byref(serial)))
+        else:
+            a = np.asarray(points)
+            n = len(a)
+            if a.dtype == np.float32 and a.ndim == 2 and a.shape[1] == 4 and a.flags.c_contiguous:
+                lay, ptr = self.PTS_F32_XYZW, a.ctypes.data
+            elif a.dtype == np.float32 and a.ndim == 2 and a.shape[1] == 3 and a.flags.c_contiguous:
+                lay, ptr = self.PTS_F32_XYZ, a.ctypes.data
+            elif a.dtype == np.float32 and a.ndim == 2 and a.shape[1] == 3 and n > 1 and a.T.flags.c_contiguous:
+                lay, ptr = self.PTS_F32_ROWS, a.T.ctypes.data
+            elif a.dtype == np.float64 and a.ndim == 2 and a.shape[1] == 3 and a.flags.c_contiguous:
+                lay, ptr = self.PTS_F64_XYZ, a.ctypes.data
+            else:
+                raise PcpError("voxelAddFrame takes float32 (n, 4) / (n, 3) / transposed rows or float64 (n, 3), C-contiguous")
+            self._feed_keep = a
+            check(self._lib.pcp_voxel_add(self._ctx, C.c_void_p(ptr), lay, n, size, stored, int(begin_index), int(max_points),
+                                          int(bool(filter_outliers)), int(max_staging), C.byref(serial)))
+        self._feed_clean = True          # later frames may rely on the device's own count
+        return serial.value
+
+    def voxelAddWait(self, serial):
+        """Waits for a fed frame -> its record (serial, stored_before, stored, unknown, created, staged, key_bits)."""
+        rec = _lib.VoxelFrame()
+        try:
+            check(self._lib.pcp_voxel_add_wait(self._ctx, int(serial), C.byref(rec)))
+        finally:
+            self._feed_keep = None
+        self._voxel_resident = rec.stored
+        return rec
+
+    def readStagedRows(self, rows, max_points):
+        """The rows the last stager dispatch released (what prepareDispatchVoxelStager returns), fetched on request."""
+        if rows <= 0:
+            return []
+        if self.voxel_stage_out is None or self.voxel_stage_out.shape[1] != max_points or len(self.voxel_stage_out) < rows:
+            self.voxel_stage_out = np.zeros((max(rows, 1024), max_points), dtype=np.int32)
+        check(self._lib.pcp_voxel_staged_read(self._ctx, int(rows), int(max_points), i32p(self.voxel_stage_out)))
+        return self.voxel_stage_out[:rows]
+
+    def readPointStore(self, first, n):
+        """Points [first, first + n) of the device point store as (n, 4) float32 (keepPointStore must be on)."""
+        out = np.zeros((int(n), 4), dtype=np.float32)
+        check(self._lib.pcp_voxel_store_read(self._ctx, int(first), int(n), f32p(out)))
+        return out
+
+    def readUnknownOfLastFrame(self):
+        """Global ids of the points of the last fed frame whose voxel did not exist yet (grouped by voxel)."""
+        n = C.c_int(0)
+        check(self._lib.pcp_voxel_add_unknown_read(self._ctx, None, 0, C.byref(n)))
+        ids = np.zeros(max(n.value, 1), dtype=np.int32)
+        if n.value:
+            check(self._lib.pcp_voxel_add_unknown_read(self._ctx, i32p(ids), n.value, C.byref(n)))
+        return ids[:n.value]
+
     def insertUnknownVoxels(self, max_points):
         """Voxelizer.storeUnknownPoints (Voxelizer.py:170-306) on the device for the unknown points of the
         last prepareDispatchVoxelizer call -> (stored voxels now, data rows the device has)."""
+        self._feed_clean = False
         stored, cap = C.c_int(0), C.c_int(0)
         check(self._lib.pcp_voxel_insert_unknown(self._ctx, int(max_points), C.byref(stored), C.byref(cap)))
         self._voxel_resident = stored.value
@@ -304,6 +392,7 @@ class ComputeShader:
         """:847-944 -> (unknown int32[pad16(1 + N)], debug (N, 4) float32 | None).
         unknown[0] is the count, unknown[1:1+count] the global ids of the points
         whose voxel is not in the table (in no particular order)."""
+        self._feed_clean = False
         n = len(np_points)
         unknown_len = 1 + n
         unknown_len += 16 - unknown_len % 16
@@ -343,6 +432,7 @@ class ComputeShader:
         """:761-835.  voxel_index is not uploaded here (the reference's upload is
         commented out, :772-775): the table of the last bufferVoxelIndex /
         prepareDispatchVoxelizer call is used.  voxel_statistics is updated in place."""
+        self._feed_clean = False
         if self.voxel_stage_out is None or self.voxel_stage_out.shape != (max_staging, max_points):
             self.voxel_stage_out = np.zeros((max_staging, max_points), dtype=np.int32)
         if voxel_statistics.dtype != np.float32 or not voxel_statistics.flags.c_contiguous:

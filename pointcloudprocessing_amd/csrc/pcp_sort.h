@@ -19,8 +19,8 @@ constexpr int RS_THREADS = 256;
 constexpr int RS_ROUNDS = PCP_RS_ROUNDS;
 constexpr int RS_TILE = RS_THREADS * RS_ROUNDS;
 
-static __global__ void __launch_bounds__(RS_THREADS)
-k_rs_hist(const unsigned long long* __restrict__ keys, size_t n, int shift, unsigned* __restrict__ hist, int nblk) {
+static __device__ __forceinline__ void rs_hist_body(const unsigned long long* __restrict__ keys, size_t n, int shift,
+                                                    unsigned* __restrict__ hist, int nblk) {
     __shared__ unsigned h[256];
     h[threadIdx.x] = 0;
     __syncthreads();
@@ -32,6 +32,11 @@ k_rs_hist(const unsigned long long* __restrict__ keys, size_t n, int shift, unsi
     }
     __syncthreads();
     hist[(size_t)threadIdx.x * nblk + blockIdx.x] = h[threadIdx.x];     // digit-major
+}
+
+static __global__ void __launch_bounds__(RS_THREADS)
+k_rs_hist(const unsigned long long* __restrict__ keys, size_t n, int shift, unsigned* __restrict__ hist, int nblk) {
+    rs_hist_body(keys, n, shift, hist, nblk);
 }
 
 // Inclusive prefix sum over the 256 threads of a block (4 waves): DPP-free shuffles inside a wave,
@@ -89,10 +94,10 @@ static __global__ void __launch_bounds__(256) k_rs_base(const unsigned* __restri
 // a key among the tile's keys of equal digit is: waves before + earlier rounds of this wave + lower
 // lanes of this round.  The tile is then put in digit order in LDS and copied out from there: the
 // keys of one digit leave as one run of consecutive addresses instead of one 8-byte write per key.
-static __global__ void __launch_bounds__(RS_THREADS)
-k_rs_scatter(const unsigned long long* __restrict__ keys_in, const unsigned* __restrict__ vals_in, size_t n, int shift,
-             const unsigned* __restrict__ hist, const unsigned* __restrict__ base, int nblk,
-             unsigned long long* __restrict__ keys_out, unsigned* __restrict__ vals_out) {
+static __device__ __forceinline__ void
+rs_scatter_body(const unsigned long long* __restrict__ keys_in, const unsigned* __restrict__ vals_in, size_t n, int shift,
+                const unsigned* __restrict__ hist, const unsigned* __restrict__ base, int nblk,
+                unsigned long long* __restrict__ keys_out, unsigned* __restrict__ vals_out) {
     __shared__ unsigned cnt[4][256];
     __shared__ unsigned tstart[256];       // first place of a digit in the sorted tile
     __shared__ unsigned delta[256];        // place in the tile -> place in the output, per digit (mod 2^32)
@@ -169,6 +174,62 @@ k_rs_scatter(const unsigned long long* __restrict__ keys_in, const unsigned* __r
             keys_out[pos] = key;
             vals_out[pos] = sv[p];
         }
+    }
+}
+
+static __global__ void __launch_bounds__(RS_THREADS)
+k_rs_scatter(const unsigned long long* __restrict__ keys_in, const unsigned* __restrict__ vals_in, size_t n, int shift,
+             const unsigned* __restrict__ hist, const unsigned* __restrict__ base, int nblk,
+             unsigned long long* __restrict__ keys_out, unsigned* __restrict__ vals_out) {
+    rs_scatter_body(keys_in, vals_in, n, shift, hist, base, nblk, keys_out, vals_out);
+}
+
+// ---- the same sort driven from device memory ----------------------------------------------------------
+// For callers that must not wait for the number of keys or of passes: both sit in device memory (RsCtl, written by an
+// earlier kernel of the stream), the launches are sized for a capacity, tiles beyond the keys and passes beyond the
+// needed ones leave at once.  Pass p reads buffer p & 1 and writes the other one, so the result is in buffer
+// passes & 1.  Meant for at most a few hundred tiles: one block scans all 256 digit rows.
+struct RsCtl { unsigned n; int passes; };
+
+static __global__ void __launch_bounds__(RS_THREADS)
+k_rsd_hist(const RsCtl* __restrict__ ctl, int pass, unsigned long long* const k0, unsigned long long* const k1,
+           unsigned* __restrict__ hist, int nblk) {
+    if (pass >= ctl->passes) return;
+    rs_hist_body((pass & 1) ? k1 : k0, (size_t)ctl->n, 8 * pass, hist, nblk);
+}
+
+// Thread d: exclusive prefix of hist[d][0..nblk) in place; then the exclusive prefix of the 256 digit totals to base.
+static __global__ void __launch_bounds__(256) k_rsd_scan(const RsCtl* __restrict__ ctl, int pass, unsigned* __restrict__ hist,
+                                                          int nblk, unsigned* __restrict__ base) {
+    __shared__ unsigned s4[4];
+    if (pass >= ctl->passes) return;
+    unsigned* h = hist + (size_t)threadIdx.x * nblk;
+    const int used = min(nblk, (int)((ctl->n + RS_TILE - 1) / RS_TILE));
+    unsigned run = 0;
+    for (int i = 0; i < used; ++i) { const unsigned v = h[i]; h[i] = run; run += v; }
+    unsigned total;
+    base[threadIdx.x] = block_scan256(run, s4, total) - run;
+}
+
+static __global__ void __launch_bounds__(RS_THREADS)
+k_rsd_scatter(const RsCtl* __restrict__ ctl, int pass, unsigned long long* const k0, unsigned long long* const k1,
+              unsigned* const v0, unsigned* const v1, const unsigned* __restrict__ hist, const unsigned* __restrict__ base, int nblk) {
+    if (pass >= ctl->passes) return;
+    const size_t n = (size_t)ctl->n;
+    if ((size_t)blockIdx.x * RS_TILE >= n) return;
+    const bool odd = pass & 1;
+    rs_scatter_body(odd ? k1 : k0, odd ? v1 : v0, n, 8 * pass, hist, base, nblk, odd ? k0 : k1, odd ? v0 : v1);
+}
+
+// Enqueues max_passes passes over up to n_cap keys.
+inline void radix_sort_pairs_dev(hipStream_t stream, const RsCtl* ctl, unsigned long long* k0, unsigned long long* k1, unsigned* v0,
+                                 unsigned* v1, size_t n_cap, int max_passes, unsigned* hist, unsigned* base) {
+    const int nblk = (int)((n_cap + RS_TILE - 1) / RS_TILE);
+    if (nblk == 0) return;
+    for (int p = 0; p < max_passes; ++p) {
+        hipLaunchKernelGGL(k_rsd_hist, dim3(nblk), dim3(RS_THREADS), 0, stream, ctl, p, k0, k1, hist, nblk);
+        hipLaunchKernelGGL(k_rsd_scan, dim3(1), dim3(256), 0, stream, ctl, p, hist, nblk, base);
+        hipLaunchKernelGGL(k_rsd_scatter, dim3(nblk), dim3(RS_THREADS), 0, stream, ctl, p, k0, k1, v0, v1, hist, base, nblk);
     }
 }
 

@@ -42,19 +42,45 @@ struct pcp_voxel_state {
     // point id = begin_index + i of the dispatch that brought it
     bool keep_store = false;
     float4* store = nullptr; size_t store_cap = 0, store_n = 0;
+    // ---- frame feed (pcp_voxel_add*): everything a frame needs to know sits in device memory
+    struct VoxFeed* feed = nullptr;          // device control block
+    struct pcp_voxel_frame* feed_rec = nullptr;   // pinned ring of per-frame records
+    struct pcp_voxel_frame* feed_rec_dev = nullptr;
+    hipEvent_t feed_done[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t feed_after = nullptr;          // orders the context's stream behind the stream that produced a device input
+    int feed_serial = 0;                     // frames enqueued so far
+    int feed_waited = 0;                     // frames whose record has been taken
+    int feed_known_stored = -1;              // voxels in the table after the last frame waited for (-1: not in feed mode)
+    long long feed_pending_points = 0;       // points of the frames enqueued since
+    unsigned* tile_counts = nullptr; int tile_cap = 0;   // per 256-point tile: unknown points / group heads
+    unsigned* rs_base = nullptr;
+    void* feed_in = nullptr; size_t feed_in_bytes = 0;   // staging of host input
     int last_staged = 0;     // rows the last pcp_voxel_stage call staged
     unsigned* staged_off = nullptr;          // staged_off_rows + 2: exclusive scan of the staged rows' point counts, total, error flag
     int staged_off_rows = 0;
     double* staged_xyz = nullptr; size_t staged_cap = 0;
 };
 
+// Control block of the frame feed (pcp_voxel_add*), in device memory.
+struct VoxFeed {
+    int stored;              // voxels in the table (the device's count is the authority while frames are fed)
+    int mm[6];               // min x, y, z / max x, y, z of the voxel coordinates of the frame's unknown points
+    pcp::RsCtl sort;         // unknown points, radix passes their keys need
+    int bx, by, bz;          // key layout: x in the top bx bits, then y, then z, each relative to mm[0..3)
+    int n_new, flags, frame;
+    int pad[16];
+};
+
 void pcp_voxel_state_free(pcp_voxel_state* v) {
     if (!v) return;
     void* bufs[] = {v->table, v->data, v->stat, v->stat_in, v->stage, v->unknown, v->pts, v->debug, v->counter,
                     v->table2, v->flag, v->k0, v->k1, v->v0, v->v1, v->heads, v->hist, v->totals, v->base, v->counts, v->mm,
-                    v->store, v->staged_off, v->staged_xyz};
+                    v->store, v->staged_off, v->staged_xyz, v->feed, v->feed_rec_dev, v->tile_counts, v->rs_base, v->feed_in};
     for (void* p : bufs)
         if (p) (void)hipFree(p);
+    if (v->feed_rec) (void)hipHostFree(v->feed_rec);
+    for (hipEvent_t ev : v->feed_done) if (ev) (void)hipEventDestroy(ev);
+    if (v->feed_after) (void)hipEventDestroy(v->feed_after);
     delete v;
 }
 
@@ -166,7 +192,8 @@ __global__ void __launch_bounds__(256)
 k_voxel_stage(const int4* __restrict__ table, int stored, const int* __restrict__ data, int data_rows,
               int max_points, float4* __restrict__ stat, const float4* __restrict__ stat_in, int stat_rows,
               int* __restrict__ stage, int max_staging, int stage_everything, int no_filter,
-              int* __restrict__ counter) {
+              int* __restrict__ counter, const VoxFeed* __restrict__ feed) {
+    if (feed) stored = feed->stored;                          // frame feed: the device's own count
     const int pos = blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
     bool live = pos < stored;
@@ -427,13 +454,307 @@ __global__ void k_stat_init(float4* __restrict__ stat, int first, int rows) {
     if (i < rows) stat[i] = make_float4(0.5f, 0.0f, 0.0f, 0.0f);
 }
 
-int use(pcp_ctx* c) {
+
+// ------------------------------------------------------------------------------------------
+// Frame feed: Voxelizer.addPoints (Voxelizer.py:81-133) as one stream of kernels.  The counts the
+// step-by-step entry points hand to the host between their steps live in this control block.
+// ------------------------------------------------------------------------------------------
+#define PCP_FEED_MAX_PASSES 6                // 48 key bits: 2^16 voxels per axis among a frame's unknown points
+#define PCP_FEED_RING 8
+
+__device__ __forceinline__ void feed_reset(VoxFeed* F) {
+    F->mm[0] = F->mm[1] = F->mm[2] = INT_MAX;
+    F->mm[3] = F->mm[4] = F->mm[5] = INT_MIN;
+    F->sort.n = 0; F->sort.passes = 0;
+    F->bx = F->by = F->bz = 0;
+    F->n_new = 0; F->flags = 0;
+}
+
+__global__ void k_feed_init(VoxFeed* F, int stored, int* counter) {
+    feed_reset(F);
+    F->stored = stored;
+    F->frame = 0;
+    counter[0] = 0;
+}
+
+template <int LAYOUT>
+__device__ __forceinline__ float4 feed_point(const void* __restrict__ src, const int n, const int i) {
+    if (LAYOUT == PCP_PTS_F32_XYZW) return reinterpret_cast<const float4*>(src)[i];
+    if (LAYOUT == PCP_PTS_F32_XYZ) {
+        const float* p = reinterpret_cast<const float*>(src) + 3 * (size_t)i;
+        return make_float4(p[0], p[1], p[2], 0.0f);
+    }
+    if (LAYOUT == PCP_PTS_F32_ROWS) {
+        const float* p = reinterpret_cast<const float*>(src);
+        return make_float4(p[i], p[(size_t)n + i], p[2 * (size_t)n + i], 0.0f);
+    }
+    const double* p = reinterpret_cast<const double*>(src) + 3 * (size_t)i;      // handleAddingPoints' float32 cast
+    return make_float4((float)p[0], (float)p[1], (float)p[2], 0.0f);
+}
+
+// VoxelShader.glsl:100-146 for one frame, with what the creation of new voxels needs noted on the way: a point
+// whose voxel is not in the table is flagged (not appended to a list: the list is made in point order by
+// k_feed_emit), its tile's count and the coordinate range of all such points are kept.
+template <int LAYOUT>
+__global__ void __launch_bounds__(256)
+k_feed_voxelize(const void* __restrict__ src, int n, const int4* __restrict__ table, VoxFeed* __restrict__ F,
+                int* __restrict__ data, int data_rows, int max_points, int begin_index, float voxel_size,
+                float4* __restrict__ pts, float4* __restrict__ store, unsigned char* __restrict__ flag,
+                unsigned* __restrict__ tile_counts) {
+    __shared__ int s_cnt[4], s_lo[4][3], s_hi[4][3];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int stored = F->stored;
+    bool unknown = false;
+    int3 c = make_int3(0, 0, 0);
+    if (i < n) {
+        const float4 p = feed_point<LAYOUT>(src, n, i);
+        pts[i] = p;
+        if (store) store[i] = p;
+        c = voxel_coord(p, voxel_size);
+        const int entry = find_voxel(table, stored, c.x, c.y, c.z);
+        if (entry == -1) {
+            unknown = true;
+        } else {
+            const int row = table[entry].w;
+            if ((unsigned)row < (unsigned)data_rows) {
+                const int k = atomicAdd(&data[(size_t)row * max_points], 1);
+                if (k < max_points - 1) data[(size_t)row * max_points + 1 + k] = begin_index + i;
+            }
+        }
+        flag[i] = unknown ? 1 : 0;
+    }
+    const unsigned long long bal = __ballot(unknown);
+    int lo[3] = {unknown ? c.x : INT_MAX, unknown ? c.y : INT_MAX, unknown ? c.z : INT_MAX};
+    int hi[3] = {unknown ? c.x : INT_MIN, unknown ? c.y : INT_MIN, unknown ? c.z : INT_MIN};
+    if (bal) {
+#pragma unroll
+        for (int s = 32; s > 0; s >>= 1)
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                lo[a] = min(lo[a], __shfl_xor(lo[a], s, 64));
+                hi[a] = max(hi[a], __shfl_xor(hi[a], s, 64));
+            }
+    }
+    if (lane == 0) {
+        s_cnt[w] = (int)__popcll(bal);
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { s_lo[w][a] = lo[a]; s_hi[w][a] = hi[a]; }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int total = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+        tile_counts[blockIdx.x] = (unsigned)total;
+        if (total) {
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                atomicMin(&F->mm[a], min(min(s_lo[0][a], s_lo[1][a]), min(s_lo[2][a], s_lo[3][a])));
+                atomicMax(&F->mm[3 + a], max(max(s_hi[0][a], s_hi[1][a]), max(s_hi[2][a], s_hi[3][a])));
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ int bits_for(const long long span) {      // smallest b with 2^b >= span (span >= 1)
+    int b = 0;
+    while ((1ll << b) < span) ++b;
+    return b;
+}
+
+// Sum of counts[0 .. upto) and of counts[0 .. all) by the whole block (256 threads).
+__device__ __forceinline__ void tile_prefix(const unsigned* __restrict__ counts, const int upto, const int all,
+                                            unsigned& before, unsigned& total) {
+    __shared__ unsigned s_b[4], s_t[4];
+    unsigned b = 0, t = 0;
+    for (int k = threadIdx.x; k < all; k += 256) {
+        const unsigned v = counts[k];
+        t += v;
+        if (k < upto) b += v;
+    }
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) { b += __shfl_xor(b, s, 64); t += __shfl_xor(t, s, 64); }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) { s_b[threadIdx.x >> 6] = b; s_t[threadIdx.x >> 6] = t; }
+    __syncthreads();
+    before = s_b[0] + s_b[1] + s_b[2] + s_b[3];
+    total = s_t[0] + s_t[1] + s_t[2] + s_t[3];
+}
+
+// (voxel key, point id) of every flagged point in point order (ids ascending): slot = flagged points before it.
+// Block 0 also fixes the key layout from the coordinate range and the number of radix passes it needs.
+__global__ void __launch_bounds__(256)
+k_feed_emit(const float4* __restrict__ pts, const unsigned char* __restrict__ flag, int n, const unsigned* __restrict__ tile_counts,
+            int tiles, VoxFeed* __restrict__ F, int begin_index, float voxel_size, unsigned long long* __restrict__ keys,
+            unsigned* __restrict__ vals) {
+    __shared__ unsigned s_w[4];
+    unsigned before, total;
+    tile_prefix(tile_counts, (int)blockIdx.x, tiles, before, total);
+    if (total == 0) return;                                   // nothing unknown in this frame (block-uniform)
+    const int mx = F->mm[0], my = F->mm[1], mz = F->mm[2];
+    const int bx = bits_for((long long)F->mm[3] - mx + 1), by = bits_for((long long)F->mm[4] - my + 1),
+              bz = bits_for((long long)F->mm[5] - mz + 1);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        int flags = 0;
+        if (bx + by + bz > 8 * PCP_FEED_MAX_PASSES) flags |= 1;
+        for (int a = 0; a < 3; ++a)
+            if (F->mm[a] <= -(1 << 20) || F->mm[3 + a] >= (1 << 20)) flags |= 4;     // the host statement's own limit
+        F->bx = bx; F->by = by; F->bz = bz;
+        F->flags = flags;
+        F->sort.n = flags ? 0u : total;
+        F->sort.passes = flags ? 0 : (bx + by + bz + 7) / 8;
+    }
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const bool keep = i < n && flag[i] != 0;
+    const unsigned long long bal = __ballot(keep);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) s_w[w] = (unsigned)__popcll(bal);
+    __syncthreads();
+    if (!keep) return;
+    unsigned slot = before + (unsigned)__popcll(bal & ((1ull << lane) - 1ull));
+    for (int j = 0; j < w; ++j) slot += s_w[j];
+    const int3 c = voxel_coord(pts[i], voxel_size);
+    keys[slot] = ((unsigned long long)(unsigned)(c.x - mx) << (by + bz)) | ((unsigned long long)(unsigned)(c.y - my) << bz) |
+                 (unsigned long long)(unsigned)(c.z - mz);
+    vals[slot] = (unsigned)(begin_index + i);
+}
+
+__device__ __forceinline__ int3 feed_key_coord(const unsigned long long key, const VoxFeed* F) {
+    const int by = F->by, bz = F->bz, bx = F->bx;
+    const unsigned long long kx = (bx ? (key >> (by + bz)) & ((1ull << bx) - 1ull) : 0ull);
+    const unsigned long long ky = (by ? (key >> bz) & ((1ull << by) - 1ull) : 0ull);
+    const unsigned long long kz = (bz ? key & ((1ull << bz) - 1ull) : 0ull);
+    return make_int3((int)kx + F->mm[0], (int)ky + F->mm[1], (int)kz + F->mm[2]);
+}
+
+// Group heads of the sorted keys: count per 256-key tile, then their positions in order.
+__global__ void __launch_bounds__(256)
+k_feed_heads_count(const VoxFeed* __restrict__ F, const unsigned long long* k0, const unsigned long long* k1,
+                   unsigned* __restrict__ tile_counts) {
+    __shared__ unsigned s_w[4];
+    const unsigned U = F->sort.n;
+    if ((unsigned)blockIdx.x * 256u >= U) return;
+    const unsigned long long* keys = (F->sort.passes & 1) ? k1 : k0;
+    const unsigned j = blockIdx.x * 256u + threadIdx.x;
+    const bool head = j < U && (j == 0 || keys[j] != keys[j - 1]);
+    const unsigned long long bal = __ballot(head);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = (unsigned)__popcll(bal);
+    __syncthreads();
+    if (threadIdx.x == 0) tile_counts[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+}
+
+__global__ void __launch_bounds__(256)
+k_feed_heads_emit(VoxFeed* __restrict__ F, const unsigned long long* k0, const unsigned long long* k1,
+                  const unsigned* __restrict__ tile_counts, unsigned* __restrict__ heads) {
+    __shared__ unsigned s_w[4];
+    const unsigned U = F->sort.n;
+    if ((unsigned)blockIdx.x * 256u >= U) return;             // block 0 is here whenever U > 0
+    const int tiles = (int)((U + 255u) / 256u);
+    unsigned before, total;
+    tile_prefix(tile_counts, (int)blockIdx.x, tiles, before, total);
+    if (blockIdx.x == 0 && threadIdx.x == 0) F->n_new = (int)total;
+    const unsigned long long* keys = (F->sort.passes & 1) ? k1 : k0;
+    const unsigned j = blockIdx.x * 256u + threadIdx.x;
+    const bool head = j < U && (j == 0 || keys[j] != keys[j - 1]);
+    const unsigned long long bal = __ballot(head);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) s_w[w] = (unsigned)__popcll(bal);
+    __syncthreads();
+    if (!head) return;
+    unsigned slot = before + (unsigned)__popcll(bal & ((1ull << lane) - 1ull));
+    for (int k = 0; k < w; ++k) slot += s_w[k];
+    heads[slot] = j;
+}
+
+// k_new_voxels with every size read from the control block; waves stride over the new voxels.
+__global__ void __launch_bounds__(256)
+k_feed_new_voxels(VoxFeed* __restrict__ F, const unsigned long long* k0, const unsigned long long* k1, const unsigned* v0,
+                  const unsigned* v1, const unsigned* __restrict__ heads, const int4* __restrict__ table,
+                  int4* __restrict__ table_out, int table_rows, int* __restrict__ data, int data_rows, int max_points) {
+    const int n_new = F->n_new, stored = F->stored, U = (int)F->sort.n;
+    if (n_new == 0) return;
+    const bool odd = F->sort.passes & 1;
+    const unsigned long long* keys = odd ? k1 : k0;
+    const unsigned* vals = odd ? v1 : v0;
+    const int lane = threadIdx.x & 63;
+    const int waves = (gridDim.x * blockDim.x) >> 6;
+    if (stored + n_new > table_rows || stored + n_new > data_rows) {          // capacity is reserved ahead: cannot happen
+        if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(&F->flags, 8);
+        return;
+    }
+    for (int k = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; k < n_new; k += waves) {
+        const unsigned h = heads[k];
+        const unsigned end = (k + 1 < n_new) ? heads[k + 1] : (unsigned)U;
+        const int count = (int)(end - h);
+        const int row = stored + k;
+        int* out = data + (size_t)row * max_points;
+        if (lane == 0) out[0] = count;
+        const int keep = min(count, max_points - 1);
+        for (int j = lane; j < keep; j += 64) out[1 + j] = (int)vals[h + j];
+        for (int j = keep + lane; j < max_points - 1; j += 64) out[1 + j] = 0;
+        if (lane == 0) {
+            const int3 c = feed_key_coord(keys[h], F);
+            int lo = 0, hi = stored;                       // first old entry not below c
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                const int cmp = lex_cmp(c.x, c.y, c.z, table[mid]);
+                if (cmp == 0) atomicOr(&F->flags, 2);
+                if (cmp > 0) lo = mid + 1; else hi = mid;
+            }
+            table_out[k + lo] = make_int4(c.x, c.y, c.z, row);
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256)
+k_feed_shift_old(const VoxFeed* __restrict__ F, const int4* __restrict__ table, const unsigned long long* k0,
+                 const unsigned long long* k1, const unsigned* __restrict__ heads, int4* __restrict__ table_out, int table_rows) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int stored = F->stored;
+    if (i >= stored) return;
+    const int n_new = (stored + F->n_new > table_rows) ? 0 : F->n_new;
+    const unsigned long long* keys = (F->sort.passes & 1) ? k1 : k0;
+    const int4 e = table[i];
+    int lo = 0, hi = n_new;                            // first new voxel not below e
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        const int3 c = feed_key_coord(keys[heads[mid]], F);
+        if (lex_cmp(c.x, c.y, c.z, e) < 0) lo = mid + 1; else hi = mid;
+    }
+    table_out[i + lo] = e;
+}
+
+// The frame's record; the control block is made ready for the next frame.
+__global__ void k_feed_finish(VoxFeed* __restrict__ F, int* __restrict__ counter, int serial, int table_rows,
+                              pcp_voxel_frame* __restrict__ rec) {
+    pcp_voxel_frame r;
+    r.serial = serial;
+    r.stored_before = F->stored;
+    const int created = (F->flags & (1 | 4 | 8)) ? 0 : F->n_new;
+    r.created = created;
+    r.stored = F->stored + created;
+    r.unknown = (int)F->sort.n;
+    r.staged = counter[0];
+    r.key_bits = F->bx + F->by + F->bz;
+    r.flags = F->flags;
+    *rec = r;
+    F->stored = r.stored;
+    F->frame = serial + 1;
+    feed_reset(F);
+    counter[0] = 0;
+}
+
+int feed_take(pcp_ctx* c, int serial, pcp_voxel_frame* out);
+
+// Every entry point starts here.  The step-by-step ones (drain = true) first take the records of frames still in flight
+// from pcp_voxel_add*, so that the host's notion of the table is the device's.
+int use(pcp_ctx* c, bool drain = true) {
     if (!c) return pcp_fail("null context");
     PCP_CHECK(hipSetDevice(c->device));
     if (!c->vox) {
         c->vox = new pcp_voxel_state();
         PCP_CHECK(hipMalloc(&c->vox->counter, 16 * sizeof(int)));
     }
+    if (drain && c->vox->feed_waited < c->vox->feed_serial) return feed_take(c, c->vox->feed_serial - 1, nullptr);
     return 0;
 }
 
@@ -470,6 +791,7 @@ int pcp_voxel_index_upload(pcp_ctx* c, const int32_t* voxel_index, int rows) {
     PCP_CHECK(hipMemcpyAsync(v->table, voxel_index, (size_t)rows * sizeof(int4), hipMemcpyHostToDevice, c->stream));
     PCP_CHECK(hipStreamSynchronize(c->stream));
     v->table_valid = rows;
+    v->feed_known_stored = -1;             // the device's own voxel count (frame feed) is void
     return 0;
 }
 
@@ -613,6 +935,8 @@ int pcp_voxel_reset(pcp_ctx* c) {
     v->data = nullptr;  v->data_rows = v->data_width = 0;
     v->last_unknown = -1;
     v->last_n = 0;
+    v->feed_known_stored = -1;
+    v->feed_pending_points = 0;
     return 0;
 }
 
@@ -736,6 +1060,7 @@ int pcp_voxel_insert_unknown(pcp_ctx* c, int max_points, int* new_stored, int* r
     std::swap(v->table, v->table2);
     std::swap(v->table_rows, v->table2_rows);
     v->table_valid = total;
+    v->feed_known_stored = -1;
     *new_stored = total;
     if (rows_capacity) *rows_capacity = v->data_rows;
     return 0;
@@ -819,7 +1144,7 @@ static int stage_impl(pcp_ctx* c, float* voxel_stat, int stat_rows, int stored, 
     if (stored > 0) {
         hipLaunchKernelGGL(k_voxel_stage, dim3(cdiv(stored, 256)), dim3(256), 0, c->stream, v->table, stored, v->data,
                            v->data_rows, max_points, v->stat, v->stat_in, v->stat_rows, v->stage, max_staging,
-                           stage_everything ? 1 : 0, filter_outliers ? 0 : 1, v->counter);
+                           stage_everything ? 1 : 0, filter_outliers ? 0 : 1, v->counter, (const VoxFeed*)nullptr);
         PCP_CHECK(hipGetLastError());
     }
     PCP_CHECK(hipMemcpyAsync(host_counter, v->counter, sizeof(host_counter), hipMemcpyDeviceToHost, c->stream));
@@ -913,6 +1238,316 @@ int pcp_voxel_staged_points(pcp_ctx* c, const double** xyz_dev, size_t* n_points
     if (bad) return pcp_fail("a staged row names a point the device store does not hold (%zu points stored)", v->store_n);
     *xyz_dev = v->staged_xyz;
     *n_points = total;
+    return 0;
+}
+
+}  // extern "C"
+
+// ---- frame feed ---------------------------------------------------------------------------------------
+
+namespace {
+
+// Device memory for one more frame of n points on a map of at most `stored_ub` voxels, reserved ahead: table and data rows
+// for stored_ub + n voxels (every point could found a voxel), statistics initialised for as many, the creation's scratch.
+// Only grows (doubling); a growth waits for the stream and copies what is in use.
+int feed_reserve(pcp_ctx* c, int stored_ub, int n, int max_points, int max_staging, size_t store_end) {
+    pcp_voxel_state* v = c->vox;
+    hipStream_t s = c->stream;
+    const long long need = (long long)stored_ub + n;
+    if (need > (1ll << 30) / max_points * 2) return pcp_fail("the voxel map cannot hold %lld voxels", need);
+    if (v->data && max_points != v->data_width) return pcp_fail("resident voxel data has row width %d", v->data_width);
+    if (need > v->table_rows || need > v->data_rows) {
+        long long rows = std::max(std::max(v->table_rows, v->data_rows), 4096);
+        while (rows < need) rows *= 2;
+        PCP_CHECK(hipStreamSynchronize(s));
+        if (rows > v->table_rows) {
+            int4* t = nullptr;
+            PCP_CHECK(hipMalloc(&t, (size_t)rows * sizeof(int4)));
+            if (v->table && stored_ub > 0)
+                PCP_CHECK(hipMemcpy(t, v->table, (size_t)std::min(stored_ub, v->table_rows) * sizeof(int4), hipMemcpyDeviceToDevice));
+            if (v->table) PCP_CHECK(hipFree(v->table));
+            v->table = t;
+            v->table_rows = (int)rows;
+        }
+        if (rows > v->data_rows) {
+            // rows of voxels that do not exist yet need no contents: the creation writes a new voxel's row whole
+            int* d = nullptr;
+            PCP_CHECK(hipMalloc(&d, (size_t)rows * max_points * sizeof(int)));
+            const int used = std::min(stored_ub, v->data_rows);
+            if (v->data && used > 0) PCP_CHECK(hipMemcpy(d, v->data, (size_t)used * max_points * sizeof(int), hipMemcpyDeviceToDevice));
+            if (v->data) PCP_CHECK(hipFree(v->data));
+            v->data = d;
+            v->data_rows = (int)rows;
+            v->data_width = max_points;
+        }
+    }
+    if (need > v->table2_rows) {
+        PCP_CHECK(hipStreamSynchronize(s));
+        if (v->table2) PCP_CHECK(hipFree(v->table2));
+        v->table2 = nullptr; v->table2_rows = 0;
+        PCP_CHECK(hipMalloc(&v->table2, (size_t)v->table_rows * sizeof(int4)));
+        v->table2_rows = v->table_rows;
+    }
+    if (v->table_rows > v->stat_rows) {                       // statistics for every row the table can hold, initialised once
+        float4 *bigger = nullptr, *bigger_in = nullptr;
+        PCP_CHECK(hipStreamSynchronize(s));
+        PCP_CHECK(hipMalloc(&bigger, (size_t)v->table_rows * sizeof(float4)));
+        PCP_CHECK(hipMalloc(&bigger_in, (size_t)v->table_rows * sizeof(float4)));
+        if (v->stat_valid > 0) PCP_CHECK(hipMemcpy(bigger, v->stat, (size_t)v->stat_valid * sizeof(float4), hipMemcpyDeviceToDevice));
+        if (v->stat) (void)hipFree(v->stat);
+        if (v->stat_in) (void)hipFree(v->stat_in);
+        v->stat = bigger; v->stat_in = bigger_in;
+        v->stat_rows = v->table_rows;
+    }
+    if (v->stat_valid < v->stat_rows) {
+        hipLaunchKernelGGL(k_stat_init, dim3(cdiv(v->stat_rows - v->stat_valid, 256)), dim3(256), 0, s, v->stat, v->stat_valid, v->stat_rows);
+        PCP_CHECK(hipGetLastError());
+        v->stat_valid = v->stat_rows;
+    }
+    if (max_staging != v->stage_rows || max_points != v->stage_width) {
+        int cap = 0;
+        PCP_CHECK(hipStreamSynchronize(s));
+        if (v->stage) PCP_CHECK(hipFree(v->stage));
+        v->stage = nullptr;
+        if (int e = grow(&v->stage, &cap, (size_t)max_staging * max_points, true, s)) return e;
+        v->stage_rows = max_staging;
+        v->stage_width = max_points;
+    }
+    if (n > v->pts_cap) {
+        PCP_CHECK(hipStreamSynchronize(s));
+        int cap = v->pts_cap, cap2 = v->pts_cap;
+        if (int e = grow(&v->pts, &cap, (size_t)n, false, s)) return e;
+        if (int e = grow(&v->debug, &cap2, (size_t)n, false, s)) return e;
+        v->pts_cap = cap;
+    }
+    if (n > v->ins_cap) {
+        PCP_CHECK(hipStreamSynchronize(s));
+        for (void* p : {(void*)v->flag, (void*)v->k0, (void*)v->k1, (void*)v->v0, (void*)v->v1, (void*)v->heads,
+                        (void*)v->hist, (void*)v->counts})
+            if (p) PCP_CHECK(hipFree(p));
+        v->flag = nullptr; v->k0 = v->k1 = nullptr; v->v0 = v->v1 = v->heads = v->hist = v->counts = nullptr;
+        v->ins_cap = 0;
+        const size_t cap = (size_t)n;
+        PCP_CHECK(hipMalloc(&v->flag, cap));
+        PCP_CHECK(hipMalloc(&v->k0, cap * 8));
+        PCP_CHECK(hipMalloc(&v->k1, cap * 8));
+        PCP_CHECK(hipMalloc(&v->v0, cap * 4));
+        PCP_CHECK(hipMalloc(&v->v1, cap * 4));
+        PCP_CHECK(hipMalloc(&v->heads, cap * 4));
+        PCP_CHECK(hipMalloc(&v->hist, pcp::radix_hist_elems(cap) * 4));
+        PCP_CHECK(hipMalloc(&v->counts, pcp::compact_count_elems(cap) * 4));
+        v->ins_cap = n;
+    }
+    if (cdiv(n, 256) + 2 > v->tile_cap) {
+        PCP_CHECK(hipStreamSynchronize(s));
+        if (v->tile_counts) PCP_CHECK(hipFree(v->tile_counts));
+        v->tile_counts = nullptr; v->tile_cap = 0;
+        PCP_CHECK(hipMalloc(&v->tile_counts, (size_t)(cdiv(n, 256) + 2) * sizeof(unsigned)));
+        v->tile_cap = cdiv(n, 256) + 2;
+    }
+    if (!v->rs_base) PCP_CHECK(hipMalloc(&v->rs_base, 256 * sizeof(unsigned)));
+    if (v->keep_store && store_end > v->store_cap) {          // doubling, like the host store (Voxelizer.py:402-416)
+        size_t cap = v->store_cap ? v->store_cap : (size_t)1 << 20;
+        while (cap < store_end) cap *= 2;
+        float4* bigger = nullptr;
+        PCP_CHECK(hipStreamSynchronize(s));
+        PCP_CHECK(hipMalloc(&bigger, cap * sizeof(float4)));
+        if (v->store_n) PCP_CHECK(hipMemcpy(bigger, v->store, v->store_n * sizeof(float4), hipMemcpyDeviceToDevice));
+        if (v->store) (void)hipFree(v->store);
+        v->store = bigger;
+        v->store_cap = cap;
+    }
+    return 0;
+}
+
+int feed_enqueue(pcp_ctx* c, const void* pts_dev, int layout, int n, float voxel_size, int stored, int begin_index, int max_points,
+                 int filter_outliers, int max_staging, int* serial) {
+    pcp_voxel_state* v = c->vox;
+    hipStream_t s = c->stream;
+    if (!v->feed) {
+        PCP_CHECK(hipMalloc(&v->feed, sizeof(VoxFeed)));
+        PCP_CHECK(hipMalloc(&v->feed_rec_dev, PCP_FEED_RING * sizeof(pcp_voxel_frame)));
+        PCP_CHECK(hipHostMalloc((void**)&v->feed_rec, PCP_FEED_RING * sizeof(pcp_voxel_frame)));
+        for (int k = 0; k < PCP_FEED_RING; ++k) PCP_CHECK(hipEventCreateWithFlags(&v->feed_done[k], hipEventDisableTiming));
+    }
+    if (v->feed_serial - v->feed_waited >= PCP_FEED_RING)          // the ring is full: the oldest frame is taken first
+        if (int e = feed_take(c, v->feed_waited, nullptr)) return e;
+    if (stored >= 0) {
+        if (v->feed_serial != v->feed_waited)
+            return pcp_fail("stored = %d given while %d fed frames have not been waited for: pass -1", stored, v->feed_serial - v->feed_waited);
+        if (stored > v->table_valid) return pcp_fail("stored = %d, resident table has %d rows", stored, v->table_valid);
+        // step-by-step calls may have run since the last fed frame: the control block starts afresh
+        hipLaunchKernelGGL(k_feed_init, dim3(1), dim3(1), 0, s, v->feed, stored, v->counter);
+        PCP_CHECK(hipGetLastError());
+        v->feed_known_stored = stored;
+        v->feed_pending_points = 0;
+    } else if (v->feed_known_stored < 0) {
+        return pcp_fail("stored = -1 needs a frame fed before (the device does not hold the voxel count yet)");
+    }
+    const long long ub = (long long)v->feed_known_stored + v->feed_pending_points;
+    if (ub + n > INT_MAX / 2) return pcp_fail("too many voxels");
+    const size_t store_end = (size_t)begin_index + (size_t)n;
+    if (int e = feed_reserve(c, (int)ub, n, max_points, max_staging, store_end)) return e;
+    const int tiles = cdiv(n, 256);
+    float4* store = v->keep_store ? v->store + begin_index : nullptr;
+    const dim3 grid(tiles), block(256);
+#define PCP_FEED_LAUNCH(L) hipLaunchKernelGGL((k_feed_voxelize<L>), grid, block, 0, s, pts_dev, n, v->table, v->feed, v->data, v->data_rows, \
+                                              max_points, begin_index, voxel_size, v->pts, store, v->flag, v->tile_counts)
+    if (layout == PCP_PTS_F32_XYZW) PCP_FEED_LAUNCH(PCP_PTS_F32_XYZW);
+    else if (layout == PCP_PTS_F32_XYZ) PCP_FEED_LAUNCH(PCP_PTS_F32_XYZ);
+    else if (layout == PCP_PTS_F32_ROWS) PCP_FEED_LAUNCH(PCP_PTS_F32_ROWS);
+    else PCP_FEED_LAUNCH(PCP_PTS_F64_XYZ);
+#undef PCP_FEED_LAUNCH
+    PCP_CHECK(hipGetLastError());
+    if (v->keep_store && store_end > v->store_n) v->store_n = store_end;
+    // the stager on the table as the frame found it (per-frame mode: the neighbour snapshot is not read)
+    const int stage_blocks = cdiv((int)std::max(ub, 1ll), 256);
+    hipLaunchKernelGGL(k_voxel_stage, dim3(stage_blocks), dim3(256), 0, s, v->table, 0, v->data, v->data_rows, max_points, v->stat,
+                       v->stat_in, v->stat_rows, v->stage, max_staging, 0, filter_outliers ? 0 : 1, v->counter, (const VoxFeed*)v->feed);
+    // the new voxels
+    hipLaunchKernelGGL(k_feed_emit, grid, block, 0, s, v->pts, v->flag, n, v->tile_counts, tiles, v->feed, begin_index, voxel_size,
+                       v->k0, v->v0);
+    PCP_CHECK(hipGetLastError());
+    pcp::radix_sort_pairs_dev(s, &v->feed->sort, v->k0, v->k1, v->v0, v->v1, (size_t)n, PCP_FEED_MAX_PASSES, v->hist, v->rs_base);
+    hipLaunchKernelGGL(k_feed_heads_count, grid, block, 0, s, v->feed, v->k0, v->k1, v->tile_counts);
+    hipLaunchKernelGGL(k_feed_heads_emit, grid, block, 0, s, v->feed, v->k0, v->k1, v->tile_counts, v->heads);
+    hipLaunchKernelGGL(k_feed_new_voxels, dim3(std::min(cdiv(n, 4), 2048)), dim3(256), 0, s, v->feed, v->k0, v->k1, v->v0, v->v1,
+                       v->heads, v->table, v->table2, std::min(v->table_rows, v->table2_rows), v->data, v->data_rows, max_points);
+    hipLaunchKernelGGL(k_feed_shift_old, dim3(stage_blocks), dim3(256), 0, s, v->feed, v->table, v->k0, v->k1, v->heads, v->table2,
+                       std::min(v->table_rows, v->table2_rows));
+    PCP_CHECK(hipGetLastError());
+    std::swap(v->table, v->table2);
+    std::swap(v->table_rows, v->table2_rows);
+    const int slot = v->feed_serial % PCP_FEED_RING;
+    hipLaunchKernelGGL(k_feed_finish, dim3(1), dim3(1), 0, s, v->feed, v->counter, v->feed_serial, v->table_rows, v->feed_rec_dev + slot);
+    PCP_CHECK(hipGetLastError());
+    PCP_CHECK(hipMemcpyAsync(v->feed_rec + slot, v->feed_rec_dev + slot, sizeof(pcp_voxel_frame), hipMemcpyDeviceToHost, s));
+    PCP_CHECK(hipEventRecord(v->feed_done[slot], s));
+    v->feed_pending_points += n;
+    v->last_unknown = -1;                               // the step-by-step insertion has nothing to take from this dispatch
+    v->last_n = n; v->last_begin = begin_index; v->last_size = voxel_size;
+    if (serial) *serial = v->feed_serial;
+    v->feed_serial++;
+    return 0;
+}
+
+// Takes the records of every frame up to `serial`; fails on the first refused one.
+int feed_take(pcp_ctx* c, int serial, pcp_voxel_frame* out) {
+    pcp_voxel_state* v = c->vox;
+    if (serial < 0 || serial >= v->feed_serial) return pcp_fail("frame %d has not been fed", serial);
+    if (serial < v->feed_serial - PCP_FEED_RING) return pcp_fail("the record of frame %d has been overwritten", serial);
+    int bad = -1, bad_flags = 0;
+    while (v->feed_waited <= serial) {
+        const int slot = v->feed_waited % PCP_FEED_RING;
+        PCP_CHECK(hipEventSynchronize(v->feed_done[slot]));
+        const pcp_voxel_frame r = v->feed_rec[slot];
+        v->feed_known_stored = r.stored;
+        v->table_valid = r.stored;
+        v->last_staged = r.staged;
+        v->feed_waited++;
+        if (r.flags && bad < 0) { bad = r.serial; bad_flags = r.flags; }
+    }
+    // points of frames still in flight may yet found voxels
+    v->feed_pending_points = 0;
+    for (int k = v->feed_waited; k < v->feed_serial; ++k) v->feed_pending_points += v->ins_cap;   // an upper bound per frame
+    if (out) *out = v->feed_rec[serial % PCP_FEED_RING];
+    if (bad >= 0) {
+        if (bad_flags & 4) return pcp_fail("frame %d: voxel coordinate beyond +-2^20", bad);
+        if (bad_flags & 1) return pcp_fail("frame %d: its unknown points span more than 2^16 voxels along an axis (use pcp_voxelize + "
+                                           "pcp_voxel_insert_unknown for such a frame); no voxel was created for them", bad);
+        if (bad_flags & 2) return pcp_fail("frame %d: an unknown point's voxel is already in the table", bad);      // Voxelizer.py:228-229
+        return pcp_fail("frame %d: the reserved capacity did not hold its new voxels", bad);
+    }
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int pcp_voxel_add_dev(pcp_ctx* c, const void* pts_dev, int layout, int n, float voxel_size, int stored, int begin_index,
+                      int max_points, int filter_outliers, int max_staging, void* after_stream, int* serial) {
+    if (int e = use(c, false)) return e;
+    if (!pts_dev) return pcp_fail("null points");
+    if (layout != PCP_PTS_F32_XYZW && layout != PCP_PTS_F32_XYZ && layout != PCP_PTS_F32_ROWS && layout != PCP_PTS_F64_XYZ)
+        return pcp_fail("unknown point layout %d", layout);
+    if (n < 1) return pcp_fail("no points to voxelize");
+    if (!(voxel_size > 0.0f)) return pcp_fail("voxel_size must be positive");
+    if (max_points < 2 || max_staging < 1) return pcp_fail("bad sizes");
+    if (begin_index < 0) return pcp_fail("begin_index must not be negative");
+    pcp_voxel_state* v = c->vox;
+    if (after_stream && (hipStream_t)after_stream != c->stream) {
+        if (!v->feed_after) PCP_CHECK(hipEventCreateWithFlags(&v->feed_after, hipEventDisableTiming));
+        PCP_CHECK(hipEventRecord(v->feed_after, (hipStream_t)after_stream));
+        PCP_CHECK(hipStreamWaitEvent(c->stream, v->feed_after, 0));
+    }
+    return feed_enqueue(c, pts_dev, layout, n, voxel_size, stored, begin_index, max_points, filter_outliers, max_staging, serial);
+}
+
+int pcp_voxel_add(pcp_ctx* c, const void* pts_host, int layout, int n, float voxel_size, int stored, int begin_index,
+                  int max_points, int filter_outliers, int max_staging, int* serial) {
+    if (int e = use(c, false)) return e;
+    if (!pts_host) return pcp_fail("null points");
+    if (layout != PCP_PTS_F32_XYZW && layout != PCP_PTS_F32_XYZ && layout != PCP_PTS_F32_ROWS && layout != PCP_PTS_F64_XYZ)
+        return pcp_fail("unknown point layout %d", layout);
+    if (n < 1) return pcp_fail("no points to voxelize");
+    pcp_voxel_state* v = c->vox;
+    const size_t bytes = (size_t)n * (layout == PCP_PTS_F64_XYZ ? 24 : (layout == PCP_PTS_F32_XYZW ? 16 : 12));
+    if (bytes > v->feed_in_bytes) {
+        PCP_CHECK(hipStreamSynchronize(c->stream));
+        if (v->feed_in) PCP_CHECK(hipFree(v->feed_in));
+        v->feed_in = nullptr; v->feed_in_bytes = 0;
+        size_t cap = (size_t)1 << 22;
+        while (cap < bytes) cap *= 2;
+        PCP_CHECK(hipMalloc(&v->feed_in, cap));
+        v->feed_in_bytes = cap;
+    }
+    PCP_CHECK(hipMemcpyAsync(v->feed_in, pts_host, bytes, hipMemcpyHostToDevice, c->stream));
+    return pcp_voxel_add_dev(c, v->feed_in, layout, n, voxel_size, stored, begin_index, max_points, filter_outliers, max_staging,
+                             nullptr, serial);
+}
+
+int pcp_voxel_add_wait(pcp_ctx* c, int serial, pcp_voxel_frame* out) {
+    if (int e = use(c, false)) return e;
+    if (!c->vox->feed) return pcp_fail("no frame has been fed");
+    return feed_take(c, serial, out);
+}
+
+int pcp_voxel_add_unknown_read(pcp_ctx* c, int32_t* ids, int capacity, int* count) {
+    if (int e = use(c, false)) return e;
+    pcp_voxel_state* v = c->vox;
+    if (!count) return pcp_fail("null count");
+    if (!v->feed || v->feed_serial == 0) return pcp_fail("no frame has been fed");
+    pcp_voxel_frame r;
+    if (int e = feed_take(c, v->feed_serial - 1, &r)) return e;
+    *count = r.unknown;
+    if (r.unknown == 0 || !ids) return 0;               // ids == NULL asks for the count alone
+    if (capacity < r.unknown) return pcp_fail("%d unknown points do not fit a list of %d", r.unknown, capacity);
+    const int passes = (r.key_bits + 7) / 8;
+    PCP_CHECK(hipMemcpyAsync(ids, (passes & 1) ? v->v1 : v->v0, (size_t)r.unknown * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    PCP_CHECK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int pcp_voxel_store_read(pcp_ctx* c, long long first, int n, float* xyzw) {
+    if (int e = use(c)) return e;
+    pcp_voxel_state* v = c->vox;
+    if (n == 0) return 0;
+    if (!xyzw || n < 0 || first < 0) return pcp_fail("bad arguments");
+    if (!v->keep_store) return pcp_fail("the device point store is off (pcp_voxel_store_enable)");
+    if ((size_t)first + (size_t)n > v->store_n) return pcp_fail("points [%lld, %lld) requested, %zu stored", first, first + n, v->store_n);
+    PCP_CHECK(hipMemcpyAsync(xyzw, v->store + first, (size_t)n * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
+    PCP_CHECK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int pcp_voxel_staged_read(pcp_ctx* c, int rows, int max_points, int32_t* stage_out) {
+    if (int e = use(c)) return e;
+    pcp_voxel_state* v = c->vox;
+    if (rows == 0) return 0;
+    if (!stage_out || rows < 0 || !v->stage || rows > v->stage_rows || max_points != v->stage_width) return pcp_fail("bad staged row range");
+    PCP_CHECK(hipMemcpyAsync(stage_out, v->stage, (size_t)rows * max_points * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    PCP_CHECK(hipStreamSynchronize(c->stream));
     return 0;
 }
 

@@ -69,6 +69,13 @@ class DeviceFrame:
         check(self._lib.pcp_frame_read(self._f, f64p(xyz), f32p(inten)))
         return (xyz, inten) if intensities else xyz
 
+    def points_dev(self):
+        """(device address of the resident float64 cloud, n rows of 3; number of points).  The frame's work is complete
+        when this returns; the address is valid until the next call that changes the frame."""
+        ptr, n = C.c_void_p(), C.c_size_t(0)
+        check(self._lib.pcp_frame_points_dev(self._f, C.byref(ptr), C.byref(n)))
+        return int(ptr.value or 0), int(n.value)
+
     # -- hand-over to a registration context ------------------------------------------------
     def as_target(self, compute, scan_lines, origin, point_to_plane=True):
         """prepareLS / preparePointPlane of `compute` with this frame as points_a."""

@@ -17,7 +17,31 @@ merge below runs on the host instead.
 import numpy as np
 
 
+class _StagedRows:
+    """The rows a fed frame's stager dispatch released: their number is known from the frame's record, the rows
+    themselves are fetched from the device when somebody reads one (a device sink never does)."""
+
+    def __init__(self, compute, count, max_points):
+        self._compute, self._count, self._max_points, self._rows = compute, int(count), max_points, None
+
+    def __len__(self):
+        return self._count
+
+    def _fetch(self):
+        if self._rows is None:
+            self._rows = self._compute.readStagedRows(self._count, self._max_points) if self._count else []
+        return self._rows
+
+    def __iter__(self):
+        return iter(self._fetch())
+
+    def __getitem__(self, k):
+        return self._fetch()[k]
+
+
 class Voxelizer:
+
+    feed_frames = True        # addPoints as one enqueue + one wait when the map lives on the device; False: step by step
 
     def __init__(self, compute_shader, renderer=None, voxman=None):
         self.voxel_size = None
@@ -26,6 +50,7 @@ class Voxelizer:
         self.renderer = renderer
         self.voxman = voxman              # render hand-off object with frameVoxelized(points, colors, separate)
 
+        self._index_stale = False
         self.voxel_index = None           # (M, 4) int32: vx, vy, vz, data row; sorted; grows x2
         self._rows_stale = False
         self.voxel_data = None            # (M, max_points) int32: [0] count, [1:] point ids
@@ -52,6 +77,20 @@ class Voxelizer:
     # even written when voxels are created -- touching one count in every 4 KB row of a lazily zeroed
     # array costs a page fault per voxel, more than the whole device side of a frame -- and is instead
     # read back when somebody looks at it.
+    # The table too, once whole frames are fed (addPoints -> ComputeShader.voxelAddFrame): the device merges the new
+    # voxels into its table and the host copy is fetched when somebody looks at it.
+    @property
+    def voxel_index(self):
+        if self._index_stale and self._voxel_index is not None:
+            self.compute.readVoxelIndex(self.stored_voxels, self._voxel_index)
+            self._index_stale = False
+        return self._voxel_index
+
+    @voxel_index.setter
+    def voxel_index(self, value):
+        self._voxel_index = value
+        self._index_stale = False
+
     @property
     def voxel_data(self):
         if self._rows_stale and self._voxel_data is not None:
@@ -83,8 +122,20 @@ class Voxelizer:
         if getattr(self, "inited", False) and getattr(self.compute, "resident_statistics", False):
             self.compute.resident_statistics = False
 
+    def _detach_from_device(self):
+        """Called by the ComputeShader before another map replaces this one on the device: every mirror that would have
+        been fetched on demand is fetched now."""
+        if not self.inited or self.stored_voxels is None:
+            return
+        if self._index_stale and self._voxel_index is not None:
+            self.voxel_index
+        if self._rows_stale and self._voxel_data is not None:
+            self._pull_rows()
+        if self._stats_stale and self._voxel_stats is not None:
+            self.voxel_stats
+
     def _pull_rows(self):
-        rows = len(self.voxel_index)
+        rows = len(self._voxel_index)
         if len(self._voxel_data) < rows:        # rows past stored_voxels are zero, on the device too
             self._voxel_data = np.zeros((rows, self.max_points), dtype=np.int32)
         self.compute.getFullVoxelData(self.stored_voxels, self.max_points, self._voxel_data)
@@ -103,7 +154,10 @@ class Voxelizer:
         self.voxel_size = np.array([voxel_size]).astype(np.float32)
         self._rows_stale = False
         if hasattr(self.compute, "voxelReserve"):
-            self.compute.voxelReserve(len(self.voxel_index), self.max_points)
+            try:
+                self.compute.voxelReserve(len(self._voxel_index), self.max_points, owner=self)
+            except TypeError:                       # a compute object with the older signature
+                self.compute.voxelReserve(len(self._voxel_index), self.max_points)
             self.realloc_needed = False
             self.compute.resident_statistics = True     # fresh map: every voxel starts from the default statistics
             self._map_epoch = getattr(self.compute, "voxel_map_epoch", None)
@@ -126,12 +180,39 @@ class Voxelizer:
         self.added_points = self.added_colors = None
 
     # ------------------------------------------------------------------ per-frame entry (:81-165)
+    def _can_feed(self):
+        """True when the whole frame can go to the device as one enqueue (ComputeShader.voxelAddFrame): the map's table,
+        rows and statistics live there and nothing on the host has replaced them."""
+        c = self.compute
+        return (self.feed_frames and self.inited and hasattr(c, "voxelAddFrame") and getattr(c, "_voxel_resident", None) == self.stored_voxels
+                and bool(getattr(c, "resident_statistics", False)) and getattr(c, "voxel_map_epoch", None) == self._map_epoch)
+
+    def _took_frame(self, rec):
+        """Book-keeping after a fed frame: sizes follow the reference's growth rule, contents are fetched on demand."""
+        prev = self.stored_voxels
+        self._index_stale = self._rows_stale = self._stats_stale = True      # the device holds the contents
+        self.stored_voxels = rec.stored
+        while rec.stored >= len(self._voxel_index):
+            self._grow()
+        self.realloc_needed, self.prev_stored_voxels, self.last_run_realloc = False, prev, False
+        self._hand_off(_StagedRows(self.compute, rec.staged, self.max_points))
+
     def addPoints(self, np_points, colors, printt=False):
+        if self._can_feed():
+            # dispatch, stager and creation of the new voxels as one stream of device work, one wait (pcp_voxel_add)
+            self.handleAddingPoints(np_points, colors)
+            pts32 = self._pending[-1][1]
+            begin = self.last_added_point - len(np_points)
+            ticket = self.compute.voxelAddFrame(pts32, self.voxel_size, self.stored_voxels, begin, self.max_points,
+                                                self.filter_outliers)
+            self._took_frame(self.compute.voxelAddWait(ticket))
+            return
         self.handleAddingPoints(np_points, colors)
         pts32 = self._pending[-1][1]                   # the float32 copy the point store keeps serves the dispatch too
         begin = self.last_added_point - len(np_points)
         unknown_points, _ = self.compute.prepareDispatchVoxelizer(
-            np_points=pts32, voxel_index=self.voxel_index, voxel_data=self._voxel_data,
+            np_points=pts32, voxel_index=self.voxel_index if getattr(self.compute, "_voxel_resident", None) != self.stored_voxels
+            else self._voxel_index, voxel_data=self._voxel_data,
             voxel_size=self.voxel_size, stored_voxel_num=self.stored_voxels, begin_index=begin,
             max_points_to_store=self.max_points, realloc_needed=self.realloc_needed,
             prev_stored_voxels=self.prev_stored_voxels, debug=False)
@@ -142,13 +223,28 @@ class Voxelizer:
         self.last_run_realloc = self.realloc_needed
         self._hand_off(voxels_to_render)
 
+    def addPointsDevice(self, device_ptr, n_points, layout=8, after_stream=None):
+        """addPoints for a cloud already in device memory (layout 8: n rows of 3 float64, cast to float32 on the device as
+        handleAddingPoints does; 4: float32 rows of 4): nothing of the frame touches the host but its 32-byte record.
+        The global point store is kept on the device for such frames (ComputeShader.keepPointStore must be on for
+        added_points / getStoredPoints to be available; they are fetched on demand)."""
+        if not self._can_feed():
+            raise RuntimeError("addPointsDevice needs the voxel map resident on the device (a ComputeShader of this package, "
+                               "init() called)")
+        begin = self.last_added_point
+        self._pending.append((begin, int(n_points), None))          # a segment the host store does not hold yet
+        self.last_added_point += int(n_points)
+        ticket = self.compute.voxelAddFrame(None, self.voxel_size, self.stored_voxels, begin, self.max_points, self.filter_outliers,
+                                            device_ptr=device_ptr, n_points=n_points, layout=layout, after_stream=after_stream)
+        self._took_frame(self.compute.voxelAddWait(ticket))
+
     def _stage(self, everything):
         """One stager dispatch (:116-119, :141-152) -> the staged rows.  With the statistics resident on the device the
         host array only tells the dispatch how many rows there are."""
         resident = bool(getattr(self.compute, "resident_statistics", False))
         stats = self._voxel_stats if resident else self.voxel_stats
         out, rows = self.compute.prepareDispatchVoxelStager(
-            self.voxel_index, self.stored_voxels, self.max_points, stats,
+            self._voxel_index, self.stored_voxels, self.max_points, stats,
             filter_outliers=self.filter_outliers, stage_everything=everything)
         if resident:
             self._stats_stale = True
@@ -214,7 +310,10 @@ class Voxelizer:
 
     def _grow(self):
         """:238-252 -- double table, data and statistics."""
-        self.voxel_index = np.vstack([self.voxel_index, np.full_like(self.voxel_index, self.bigint)])
+        if self._index_stale:                # the device holds the table: only the size of the host copy changes
+            self._voxel_index = np.full((2 * len(self._voxel_index), 4), self.bigint, dtype=np.int32)
+        else:
+            self._voxel_index = np.vstack([self._voxel_index, np.full_like(self._voxel_index, self.bigint)])
         # Rows past stored_voxels are zero, so only the used rows are carried over into a freshly
         # zeroed (lazily mapped) array; when the device holds the authoritative rows the host copy is
         # stale anyway and will be read back before anybody looks at it, so only the counts move.
@@ -241,9 +340,9 @@ class Voxelizer:
         if hasattr(self.compute, "insertUnknownVoxels"):
             new_stored, _ = self.compute.insertUnknownVoxels(self.max_points)
             self._rows_stale = True
-            while new_stored >= len(self.voxel_index):
+            while new_stored >= len(self._voxel_index):
                 self._grow()                       # host arrays only: the device grew its own
-            self.compute.readVoxelIndex(new_stored, self.voxel_index)
+            self.compute.readVoxelIndex(new_stored, self._voxel_index)
             self.stored_voxels = new_stored
             return False, prev_stored
         ids = np.sort(unknown_points[1:n + 1])     # the device appends in no particular order
@@ -305,7 +404,7 @@ class Voxelizer:
         pending, self._pending = self._pending, []
         need = self.last_added_point
         if self._added_points is None:
-            first = len(pending[0][1])
+            first = pending[0][1] if isinstance(pending[0][1], int) else len(pending[0][1])
             self._added_points = np.empty((max(first * 2, 1), 4), dtype=np.float32)
             self._added_colors = np.empty((max(first * 2, 1), 3), dtype=np.float32)
         size = len(self._added_points)
@@ -319,6 +418,10 @@ class Voxelizer:
                 new[:used] = old[:used]
                 setattr(self, name, new)
         for start, pts, cols in pending:
+            if isinstance(pts, int):             # a frame fed from device memory: its points come back from the device store
+                self._added_points[start:start + pts] = self.compute.readPointStore(start, pts)
+                self._added_colors[start:start + pts] = 255.0
+                continue
             self._added_points[start:start + len(pts), :3] = pts
             # colors=None means white (np.full((n, 3), 255) in the reference), written without the temporary
             self._added_colors[start:start + len(pts)] = 255.0 if cols is None else cols

@@ -365,3 +365,129 @@ def test_statistics_stay_on_the_device_and_are_fetched_on_access(compute):
     with pytest.raises(RuntimeError, match="has been replaced"):
         lazy.voxel_stats
     eager.cleanup()
+
+
+# ------------------------------------------------------------------------------ whole frames as one enqueue (pcp_voxel_add*)
+def _map_state(v):
+    s = v.stored_voxels
+    v.refreshVoxelData()
+    data = v.voxel_data[:s].copy()
+    rows = [np.sort(data[r, 1:min(data[r, 0] + 1, v.max_points)]) for r in range(s)]
+    return v.voxel_index[:s].copy(), data[:, 0].copy(), rows, v.voxel_stats[:s].copy()
+
+
+def _raw_frames(n):
+    from pointcloudprocessing_amd import lidar
+    from tests._data import kitti_sequence_raw
+    return [lidar.frame_from_raw(r) for r in kitti_sequence_raw()[:n]]
+
+
+def test_fed_frames_equal_the_step_by_step_path(compute):
+    """Voxelizer.addPoints as one enqueue and one wait (dispatch + stager + creation of the new voxels with every count
+    left on the device) against the same frames through the step-by-step entry points (five host round trips per
+    frame): table, counts, id sets, statistics bit for bit, stored counts and staged-row counts after every frame."""
+    from pointcloudprocessing_amd import ComputeShader
+    frames = _raw_frames(6)
+    other = ComputeShader(maxPointsPerCloud=200000, maxScans=100)
+    try:
+        fed, steps = Voxelizer(compute, None), Voxelizer(other, None)
+        steps.feed_frames = False
+        for v in (fed, steps):
+            v.init(0.5)
+            v.filter_outliers = True
+        for k, f in enumerate(frames):
+            fed.addPoints(f, None)
+            steps.addPoints(f, None)
+            assert fed.stored_voxels == steps.stored_voxels and len(fed.voxel_index) == len(steps.voxel_index), k
+        ti, tc, tr, ts = _map_state(fed)
+        wi, wc, wr, ws = _map_state(steps)
+        assert np.array_equal(ti, wi) and np.array_equal(tc, wc)
+        assert np.array_equal(ts.view(np.uint32), ws.view(np.uint32))
+        full = tc >= fed.max_points
+        for r in range(len(tr)):
+            if not full[r]:
+                assert np.array_equal(tr[r], wr[r]), r
+        # a new voxel's row holds its ids ascending, as the host statement writes them
+        created_last = np.arange(fed.prev_stored_voxels, fed.stored_voxels)
+        for r in created_last[:50]:
+            k = min(fed.voxel_data[r, 0] + 1, fed.max_points)
+            assert np.all(np.diff(fed.voxel_data[r, 1:k]) > 0)
+        # the global point store the rows index into
+        assert np.array_equal(fed.added_points[:fed.last_added_point, :3], steps.added_points[:steps.last_added_point, :3])
+        # the final full staging works on the fed map as on the other
+        fed.stageAllRemaningVoxels()
+        steps.stageAllRemaningVoxels()
+        assert np.array_equal(fed.voxel_stats[:fed.stored_voxels].view(np.uint32), steps.voxel_stats[:steps.stored_voxels].view(np.uint32))
+    finally:
+        other.cleanup()
+
+
+def test_frames_fed_from_device_memory_and_without_waiting(compute):
+    """The raw entry points: frames in device memory as float64 (cast on the device like handleAddingPoints), four of
+    them enqueued before the first wait, the device's own voxel count carried from frame to frame (stored = -1); the
+    records and the map equal those of the Voxelizer fed the same clouds from the host one at a time."""
+    from pointcloudprocessing_amd import ComputeShader, _lib
+    from pointcloudprocessing_amd.frame import DeviceFrame
+    lib = compute._lib
+    frames = _raw_frames(4)
+    other = ComputeShader(maxPointsPerCloud=200000, maxScans=100)
+    dev = [DeviceFrame(200000) for _ in frames]
+    try:
+        want = Voxelizer(other, None)
+        want.init(0.5)
+        want.filter_outliers = False
+        recs_want = []
+        for f in frames:
+            before = want.stored_voxels
+            want.addPoints(f, None)
+            recs_want.append((before, want.stored_voxels))
+        v = Voxelizer(compute, None)
+        v.init(0.5)
+        compute.keepPointStore(True)
+        tickets, begin = [], 0
+        for d, f in zip(dev, frames):
+            d.upload(f)
+            ptr, n = d.points_dev()
+            t = C.c_int(-1)
+            _lib.check(lib.pcp_voxel_add_dev(compute._ctx, C.c_void_p(ptr), 8, n, 0.5, 0 if not tickets else -1, begin, 1024, 0, 1024,
+                                             None, C.byref(t)))
+            tickets.append(t.value)
+            begin += n
+        for k, t in enumerate(tickets):
+            rec = _lib.VoxelFrame()
+            _lib.check(lib.pcp_voxel_add_wait(compute._ctx, t, C.byref(rec)))
+            assert (rec.stored_before, rec.stored) == recs_want[k] and rec.created == rec.stored - rec.stored_before and rec.flags == 0
+            assert rec.unknown >= rec.created and rec.serial == t
+        s = want.stored_voxels
+        table = np.zeros((s, 4), np.int32)
+        compute.readVoxelIndex(s, table)
+        assert np.array_equal(table, want.voxel_index[:s])
+        assert np.array_equal(compute.readVoxelCounts(0, s), want.voxel_data[:s, 0])
+        # the unknown points of the last frame, on request: the ids the host's np.unique grouping would take
+        ids = compute.readUnknownOfLastFrame()
+        coords = want.vectorizedGetVoxelCoord(want.added_points[ids][:, :3])
+        new_rows = want.voxel_index[:s][want.voxel_index[:s, 3] >= recs_want[-1][0]]
+        assert len(ids) == rec.unknown and len(np.unique(coords, axis=0)) == rec.created == len(new_rows)
+        assert np.array_equal(np.unique(coords, axis=0), new_rows[:, :3])
+        # the device point store holds what handleAddingPoints casts
+        got = compute.readPointStore(0, begin)
+        assert np.array_equal(got[:, :3], want.added_points[:begin, :3])
+    finally:
+        for d in dev:
+            d.cleanup()
+        other.cleanup()
+
+
+def test_a_frame_too_wide_for_the_keys_is_refused(compute):
+    v = Voxelizer(compute, None)
+    v.init(0.5)
+    pts = np.array([[0.1, 0.1, 0.1], [0.2, 0.2, 0.2], [40000.0, 0.1, 0.1], [0.1, 39000.0, 0.3], [0.3, 0.1, 38000.0]])
+    with pytest.raises(PcpError, match="span more than 2\\^16 voxels"):
+        v.addPoints(pts, None)
+    # the map is unchanged and usable
+    v2 = Voxelizer(compute, None)
+    v2.init(0.5)
+    v2.addPoints(pts[:2], None)
+    assert v2.stored_voxels == 1
+    with pytest.raises(PcpError, match="beyond \\+-2\\^20"):
+        v2.addPoints(np.array([[0.1, 0.1, 0.1], [600000.0, 0.0, 0.0]]), None)
