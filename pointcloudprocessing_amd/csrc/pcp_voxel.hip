@@ -21,6 +21,7 @@
 struct pcp_voxel_state {
     int4* table = nullptr;   int table_rows = 0, table_valid = 0;   // capacity / rows of the last upload
     int* data = nullptr;     int data_rows = 0, data_width = 0;
+    bool data_dirty = false; // rows hold the ids of a map that has been reset
     float4 *stat = nullptr, *stat_in = nullptr;   int stat_rows = 0;
     int stat_valid = 0;      // rows of `stat` that hold statistics (resident mode); rows behind them are made (0.5, 0, 0, 0)
     int* stage = nullptr;    int stage_rows = 0, stage_width = 0;
@@ -926,13 +927,13 @@ int pcp_voxel_reset(pcp_ctx* c) {
     if (int e = use(c)) return e;
     pcp_voxel_state* v = c->vox;
     PCP_CHECK(hipStreamSynchronize(c->stream));
-    if (v->table) PCP_CHECK(hipFree(v->table));
-    if (v->data) PCP_CHECK(hipFree(v->data));
-    if (v->store) PCP_CHECK(hipFree(v->store));
-    v->store = nullptr; v->store_cap = v->store_n = 0; v->last_staged = 0;
+    // The map is forgotten, its buffers are kept for the next one (a map of 100 k voxels holds 400 MB of rows: freeing
+    // and allocating them again per map costs more than a frame).  Rows the next map has not written hold old ids: they
+    // belong to no voxel until the creation of a voxel rewrites its row whole, and pcp_voxel_reserve clears what it hands out.
+    v->store_n = 0; v->last_staged = 0;
     v->stat_valid = 0;
-    v->table = nullptr; v->table_rows = v->table_valid = 0;
-    v->data = nullptr;  v->data_rows = v->data_width = 0;
+    v->table_valid = 0;
+    v->data_dirty = v->data != nullptr;
     v->last_unknown = -1;
     v->last_n = 0;
     v->feed_known_stored = -1;
@@ -944,8 +945,12 @@ int pcp_voxel_reserve(pcp_ctx* c, int rows, int max_points) {
     if (int e = use(c)) return e;
     pcp_voxel_state* v = c->vox;
     if (rows < 1 || max_points < 2) return pcp_fail("bad sizes");
-    if (v->data && max_points != v->data_width) return pcp_fail("resident voxel data has row width %d", v->data_width);
     PCP_CHECK(hipStreamSynchronize(c->stream));
+    if (v->data && max_points != v->data_width) {
+        if (v->table_valid > 0) return pcp_fail("resident voxel data has row width %d", v->data_width);
+        PCP_CHECK(hipFree(v->data));              // buffers kept from a map of another row width that has been reset
+        v->data = nullptr; v->data_rows = v->data_width = 0; v->data_dirty = false;
+    }
     if (rows > v->table_rows) {
         int4* t = nullptr;
         PCP_CHECK(hipMalloc(&t, (size_t)rows * sizeof(int4)));
@@ -954,6 +959,10 @@ int pcp_voxel_reserve(pcp_ctx* c, int rows, int max_points) {
         if (v->table) PCP_CHECK(hipFree(v->table));
         v->table = t;
         v->table_rows = rows;
+    }
+    if (v->data_dirty && v->data) {            // buffers kept from a map that has been reset: the rows handed out start empty
+        PCP_CHECK(hipMemsetAsync(v->data, 0, (size_t)std::min(rows, v->data_rows) * max_points * sizeof(int), c->stream));
+        v->data_dirty = false;
     }
     if (rows > v->data_rows) {
         int* d = nullptr;
