@@ -561,6 +561,52 @@ int pcp_seq_collect_poses(pcp_seq* seq, int ticket, double* t_opt, double* R_opt
  * they processed. */
 int pcp_seq_profile_enable(pcp_seq* seq, int on);
 int pcp_seq_profile_read(pcp_seq* seq, float* ls_ms, int* launches, long long* points);
+/* ---------------------------------------------------------------------------
+ * The per-frame driver loop of a drive as one stream of device work.
+ * EnvironmentConstructor.calculateTransition_imu (EnvironmentConstructor.py:154-265) handles a frame on the host: guess =
+ * refined position of the previous frame + dead-reckoned step (:198-206), placed = (imu_rotation @ cloud.T).T + guess
+ * (:209), full_pt2pl / full_pt2pt against the reference cloud about its origin (:223-230; the frame that closes a block
+ * of reset_every frames runs closing_iterations full iterations, :216-220), refined = (R_opt @ placed.T).T - t_opt and
+ * position = R_opt @ guess - t_opt (:233-235), voxelizer.addPoints(refined) (:245), and every reset_every-th frame the
+ * refined cloud and position replace the reference cloud and origin (:250-254).  A pcp_chain keeps all of that on the
+ * device across frames and submissions: positions, the prepared reference (ring table, unit vectors, normals) and its
+ * origin never visit the host, the refined clouds go to the voxel feed (pcp_voxel_add_dev) of voxel_ctx on that
+ * context's stream while the next frame is registered.  Frame 0 of a drive is not registered: turned by its IMU
+ * attitude it is the first reference cloud about the origin (0, 0, 0) (:168-189).
+ * ------------------------------------------------------------------------- */
+typedef struct pcp_chain pcp_chain;
+
+/* Buffers for submissions of up to max_frames frames of up to max_points raw points each. */
+int pcp_chain_create(int device, int max_frames, int max_points, int max_scans, pcp_chain** out);
+int pcp_chain_destroy(pcp_chain* chain);
+/* Forget the drive: the next frame submitted is frame 0 of a new one (EnvironmentConstructor.init :45-60). */
+int pcp_chain_reset(pcp_chain* chain);
+/* Enqueue the next n_frames raw frames of the drive (raw_xyzi[f]: n_raw[f] float32 rows x, y, z, intensity; ego filter
+ * |p| > min_range and rotation R9 as pcp_seq_submit).  imu holds 12 float64 per frame: the IMU rotation of the frame
+ * (row-major, current_rotation of :164) and its dead-reckoned step (getDeltaVelocity :90-95; ignored for frame 0 of a
+ * drive).  mode / iterations / tol as pcp_icp_launch for ordinary frames (<= 32 iterations).  voxel_ctx (or NULL: no map) receives every
+ * frame's final cloud through pcp_voxel_add_dev with voxel_size / voxel_max_points / filter_outliers / max_staging;
+ * voxel_stored and voxel_begin_index are that call's `stored` and `begin_index` for the first frame fed (the following
+ * frames continue from the device's own count and from the points fed so far); first_voxel_serial (or NULL) receives
+ * the first frame's ticket for pcp_voxel_add_wait, the others follow consecutively.  The call waits once, for the number of points each frame keeps
+ * (returned in n_points, n_frames ints, may be NULL), then enqueues and returns a ticket; at most two submissions may
+ * be in flight.  Raw buffers must stay valid until the ticket is collected. */
+int pcp_chain_submit(pcp_chain* chain, const float* const* raw_xyzi, const int* n_raw, int n_frames, float min_range,
+                     const double* R9, const double* imu, int mode, int iterations, float tol, int closing_iterations,
+                     int reset_every, pcp_ctx* voxel_ctx, float voxel_size, int voxel_stored, int voxel_begin_index,
+                     int voxel_max_points, int filter_outliers, int max_staging, int* ticket, int* n_points,
+                     int* first_voxel_serial);
+/* Wait for a submission: per frame the estimated position (guess, 3 float64), the refined position (3), the pose
+ * full_pt2pl returned (t_opt 3, R_opt 9 row-major; identity for frame 0 of a drive), the steps (dx_stride_iters x 6
+ * float32, zero beyond iters[f]), iterations and convergence flag; chain_ms (or NULL) the device time of the
+ * submission's chain on its stream.  Any output may be NULL.  Fails (after filling the outputs) when a reference cloud
+ * could not be prepared (more scan lines than max_scans, none) or a frame met singular normal equations; such a frame
+ * stays where the IMU put it. */
+int pcp_chain_collect(pcp_chain* chain, int ticket, double* guess, double* position, double* t_opt, double* R_opt,
+                      float* dx_trace, int dx_stride_iters, int* iters, int* converged, float* chain_ms);
+/* The final cloud of frame `frame` of a collected submission (n x 3 float64: what went to the voxel map), while its
+ * buffers have not been reused by the submission after the next. */
+int pcp_chain_read_refined(pcp_chain* chain, int ticket, int frame, double* xyz, int n);
 /* Page-locked host memory for buffers handed to pcp_seq_submit (hipHostMalloc / hipHostFree). */
 int pcp_host_alloc(size_t bytes, void** out);
 int pcp_host_free(void* p);

@@ -15,3 +15,4 @@ from .oxts import OXTS, OxtsDataReader  # noqa: F401
 from .voxelizer import Voxelizer  # noqa: F401
 from .sequence import PinnedFrames, SequencePipeline  # noqa: F401
 from .map_sink import MapSink  # noqa: F401
+from .chain import OdometryChain, chain_odometry  # noqa: F401

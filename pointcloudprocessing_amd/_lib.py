@@ -153,6 +153,14 @@ SIGNATURES = {
     "pcp_seq_collect_poses": (C.c_int, [C.c_void_p, C.c_int, _f64p, _f64p, _f32p, C.c_int, _i32p, _i32p, _i32p]),
     "pcp_seq_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "pcp_seq_profile_read": (C.c_int, [C.c_void_p, _f32p, _i32p, C.POINTER(C.c_longlong)]),
+    "pcp_chain_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "pcp_chain_destroy": (C.c_int, [C.c_void_p]),
+    "pcp_chain_reset": (C.c_int, [C.c_void_p]),
+    "pcp_chain_submit": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), _i32p, C.c_int, C.c_float, _f64p, _f64p, C.c_int, C.c_int,
+                                   C.c_float, C.c_int, C.c_int, _ctx, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                   _i32p, _i32p, _i32p]),
+    "pcp_chain_collect": (C.c_int, [C.c_void_p, C.c_int, _f64p, _f64p, _f64p, _f64p, _f32p, C.c_int, _i32p, _i32p, _f32p]),
+    "pcp_chain_read_refined": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _f64p, C.c_int]),
     "pcp_host_alloc": (C.c_int, [C.c_size_t, C.POINTER(C.c_void_p)]),
     "pcp_host_free": (C.c_int, [C.c_void_p]),
     "pcp_ring_stats": (C.c_int, [_ctx, _f32p]),

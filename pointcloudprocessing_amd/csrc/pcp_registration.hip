@@ -372,8 +372,7 @@ __global__ void __launch_bounds__(PCP_BLOCK) k_ls(const LsArgs A) {
 // their lane of the first wave over all rings.  Same results; the batched launches keep ls_body (they
 // fill the GPU, and the unpruned rings would be wasted work there).
 template <int MODE, bool F64SRC>
-__global__ void __launch_bounds__(256) k_ls_quad(const LsArgs A) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+__device__ __forceinline__ void ls_quad_body(const LsArgs& A, char* smem, const unsigned block) {
     __shared__ float s_d[4][64];
     __shared__ int s_glob[4][64], s_ring[4][64];
     IcpState* __restrict__ st = A.st;
@@ -384,7 +383,7 @@ __global__ void __launch_bounds__(256) k_ls_quad(const LsArgs A) {
     const float4* s_stat;
     load_rings(smem, A.scan, A.stat, A.Z, s_scan, s_stat);
     const int t = threadIdx.x, qi = t & 63, sub = t >> 6;
-    const int i = blockIdx.x * 64 + qi;
+    const int i = block * 64 + qi;
     const bool in = i < A.n_b;
     float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
     double px = 0.0, py = 0.0, pz = 0.0;
@@ -441,7 +440,24 @@ __global__ void __launch_bounds__(256) k_ls_quad(const LsArgs A) {
         else ls_plane_values(pa, q, ld4(as_global(A.normals), nn), d, v);
     }
     const float mine = wave_tree_sum_all(v, qi);      // lane k: value k of the wave's tree sum
-    if (qi < PCP_PSTRIDE) A.partials[(size_t)blockIdx.x * PCP_PSTRIDE + qi] = mine;
+    if (qi < PCP_PSTRIDE) A.partials[(size_t)block * PCP_PSTRIDE + qi] = mine;
+}
+
+template <int MODE, bool F64SRC>
+__global__ void __launch_bounds__(256) k_ls_quad(const LsArgs A) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    ls_quad_body<MODE, F64SRC>(A, smem, blockIdx.x);
+}
+
+// The same with the descriptor in device memory: a loop whose target (ring table, origin, sizes) was made by
+// earlier kernels of the same stream, so that the host never learns them.  Launched for a capacity; blocks
+// beyond the source's size leave at once.
+template <int MODE>
+__global__ void __launch_bounds__(256) k_ls_quad_ind(const LsArgs* __restrict__ desc) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const LsArgs A = *desc;
+    if ((int)(blockIdx.x * 64) >= A.n_b) return;
+    ls_quad_body<MODE, true>(A, smem, blockIdx.x);
 }
 
 // Iteration 0 of the device loop on a freshly prepared pair searches all rings (hint -1), and with one
@@ -473,6 +489,14 @@ template <int K, bool F64SRC>
 __global__ void __launch_bounds__(PCP_BLOCK) k_first_rings(const LsArgs A) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     first_rings_body<K, F64SRC>(A, smem, blockIdx.x);
+}
+
+template <int K>
+__global__ void __launch_bounds__(PCP_BLOCK) k_first_rings_ind(const LsArgs* __restrict__ desc) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const LsArgs A = *desc;
+    if ((int)((blockIdx.x * PCP_BLOCK) / K) >= A.n_b || A.st->done) return;
+    first_rings_body<K, true>(A, smem, blockIdx.x);
 }
 
 // The same for a batch of independent pairs.
@@ -1504,3 +1528,4 @@ int pcp_timer_stop(pcp_ctx* c, float* ms) {
 }  // extern "C"
 
 #include "pcp_sequence.inl"
+#include "pcp_chain.inl"

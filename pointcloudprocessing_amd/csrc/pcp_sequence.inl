@@ -32,12 +32,23 @@ struct SeqKeepFar {       // ego filter of frame f: np.linalg.norm(float32 rows)
     }
 };
 
+// Azimuth of a point as getScanLines sees it (PointcloudIcpContainer.py:366-374): sphereProjectPoints about
+// origin + (0, 0.127, 0), atan2(z, x) of the unit vector mapped to [0, 2 pi).
+__device__ __forceinline__ double ring_azimuth(const double x, const double y, const double z, const double ox, const double oy,
+                                               const double oz) {
+    const double vx = x - ox, vy = (y - oy) - 0.127, vz = z - oz;
+    const double mag = sqrt((vx * vx + vy * vy) + vz * vz);
+    double a = atan2(vz / mag, vx / mag);
+    if (a < 0.0) a += 6.283185307179586;
+    return a;
+}
+
 struct SeqDecoded {       // rotated float64 point of frame f; targets also get their float32 padded copy
     const float4* const* raw;
     double* const* xyz;
-    float4* const* a32;           // a32[f] == nullptr for the last frame (it is nobody's target)
+    float4* const* a32;           // a32[f] == nullptr for the last frame (it is nobody's target); nullptr: no float32 copies
     const double* place;          // per frame 12 doubles (rotation Q row-major, offset g), or nullptr
-    double* const* az;            // per frame: azimuth of every kept point about the origin (getScanLines :366-374)
+    double* const* az;            // per frame: azimuth of every kept point about the origin (getScanLines :366-374); nullptr: none
     double ox, oy, oz;
     double R[9];
     __device__ void operator()(int f, size_t i, size_t slot) const {
@@ -58,13 +69,9 @@ struct SeqDecoded {       // rotated float64 point of frame f; targets also get 
         out[3 * slot + 0] = rx; out[3 * slot + 1] = ry; out[3 * slot + 2] = rz;
         // sphereProjectPoints about origin + (0, 0.127, 0), azimuth atan2(z, x) mapped to [0, 2 pi): once per point here,
         // the ring-boundary passes below only compare neighbours
-        const double vx = rx - ox, vy = (ry - oy) - 0.127, vz = rz - oz;
-        const double mag = sqrt((vx * vx + vy * vy) + vz * vz);
-        double a = atan2(vz / mag, vx / mag);
-        if (a < 0.0) a += 6.283185307179586;
-        az[f][slot] = a;
+        if (az) az[f][slot] = ring_azimuth(rx, ry, rz, ox, oy, oz);
         // ComputeShader.pad_points (:956-961) + the float32 cast of the upload
-        if (a32[f]) a32[f][slot] = make_float4((float)rx, (float)ry, (float)rz, 0.0f);
+        if (a32 && a32[f]) a32[f][slot] = make_float4((float)rx, (float)ry, (float)rz, 0.0f);
     }
 };
 

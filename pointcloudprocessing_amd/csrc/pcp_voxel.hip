@@ -51,6 +51,7 @@ struct pcp_voxel_state {
     hipEvent_t feed_after = nullptr;          // orders the context's stream behind the stream that produced a device input
     int feed_serial = 0;                     // frames enqueued so far
     int feed_waited = 0;                     // frames whose record has been taken
+    std::vector<pcp_voxel_frame> feed_history;    // the last PCP_FEED_HISTORY records taken, by serial % PCP_FEED_HISTORY
     int feed_known_stored = -1;              // voxels in the table after the last frame waited for (-1: not in feed mode)
     long long feed_pending_points = 0;       // points of the frames enqueued since
     unsigned* tile_counts = nullptr; int tile_cap = 0;   // per 256-point tile: unknown points / group heads
@@ -462,6 +463,7 @@ __global__ void k_stat_init(float4* __restrict__ stat, int first, int rows) {
 // ------------------------------------------------------------------------------------------
 #define PCP_FEED_MAX_PASSES 6                // 48 key bits: 2^16 voxels per axis among a frame's unknown points
 #define PCP_FEED_RING 8
+#define PCP_FEED_HISTORY 1024                // records of frames already waited for stay readable this long
 
 __device__ __forceinline__ void feed_reset(VoxFeed* F) {
     F->mm[0] = F->mm[1] = F->mm[2] = INT_MAX;
@@ -1444,12 +1446,18 @@ int feed_enqueue(pcp_ctx* c, const void* pts_dev, int layout, int n, float voxel
 int feed_take(pcp_ctx* c, int serial, pcp_voxel_frame* out) {
     pcp_voxel_state* v = c->vox;
     if (serial < 0 || serial >= v->feed_serial) return pcp_fail("frame %d has not been fed", serial);
-    if (serial < v->feed_serial - PCP_FEED_RING) return pcp_fail("the record of frame %d has been overwritten", serial);
+    if (serial < v->feed_waited - PCP_FEED_HISTORY) return pcp_fail("the record of frame %d has been overwritten", serial);
+    if (v->feed_history.empty()) v->feed_history.resize(PCP_FEED_HISTORY);
     int bad = -1, bad_flags = 0;
+    if (serial < v->feed_waited) {           // taken before (by an earlier wait, or by the ring filling up)
+        const pcp_voxel_frame r = v->feed_history[serial % PCP_FEED_HISTORY];
+        if (r.flags) { bad = r.serial; bad_flags = r.flags; }
+    }
     while (v->feed_waited <= serial) {
         const int slot = v->feed_waited % PCP_FEED_RING;
         PCP_CHECK(hipEventSynchronize(v->feed_done[slot]));
         const pcp_voxel_frame r = v->feed_rec[slot];
+        v->feed_history[v->feed_waited % PCP_FEED_HISTORY] = r;
         v->feed_known_stored = r.stored;
         v->table_valid = r.stored;
         v->last_staged = r.staged;
@@ -1459,7 +1467,7 @@ int feed_take(pcp_ctx* c, int serial, pcp_voxel_frame* out) {
     // points of frames still in flight may yet found voxels
     v->feed_pending_points = 0;
     for (int k = v->feed_waited; k < v->feed_serial; ++k) v->feed_pending_points += v->ins_cap;   // an upper bound per frame
-    if (out) *out = v->feed_rec[serial % PCP_FEED_RING];
+    if (out) *out = v->feed_history[serial % PCP_FEED_HISTORY];
     if (bad >= 0) {
         if (bad_flags & 4) return pcp_fail("frame %d: voxel coordinate beyond +-2^20", bad);
         if (bad_flags & 1) return pcp_fail("frame %d: its unknown points span more than 2^16 voxels along an axis (use pcp_voxelize + "

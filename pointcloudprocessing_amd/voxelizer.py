@@ -238,6 +238,32 @@ class Voxelizer:
                                             device_ptr=device_ptr, n_points=n_points, layout=layout, after_stream=after_stream)
         self._took_frame(self.compute.voxelAddWait(ticket))
 
+    # -- frames fed by a device-side producer (chain.OdometryChain): the producer enqueues pcp_voxel_add_dev itself
+    def _feed_begin(self):
+        """-> (context handle, voxel size, stored voxels or -1, begin index, row width, filter flag) for a producer that
+        feeds this map from device memory; the same conditions as addPointsDevice."""
+        if not self._can_feed():
+            raise RuntimeError("the voxel map must be resident on the device (a ComputeShader of this package, init() called)")
+        stored = -1 if self.compute._feed_clean else int(self.stored_voxels)
+        return (self.compute._ctx, float(np.asarray(self.voxel_size).reshape(-1)[0]), stored, int(self.last_added_point),
+                int(self.max_points), int(bool(self.filter_outliers)))
+
+    def _feed_noted(self, counts, first_serial):
+        """Book-keeping for frames a producer has enqueued: their points are segments of the store the host does not hold
+        (they come back from the device store when somebody looks), their tickets run from first_serial on."""
+        for n in counts:
+            self._pending.append((self.last_added_point, int(n), None))
+            self.last_added_point += int(n)
+        self.compute._feed_clean = True
+        self.__dict__.setdefault("_feed_tickets", []).append(int(first_serial) + len(counts) - 1)
+
+    def _feed_wait(self):
+        """Waits for the oldest run of enqueued frames and takes its last record (voxels stored, rows staged by the last
+        frame; the staged rows of the frames before it are not kept)."""
+        tickets = self.__dict__.get("_feed_tickets") or []
+        if tickets:
+            self._took_frame(self.compute.voxelAddWait(tickets.pop(0)))
+
     def _stage(self, everything):
         """One stager dispatch (:116-119, :141-152) -> the staged rows.  With the statistics resident on the device the
         host array only tells the dispatch how many rows there are."""
