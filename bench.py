@@ -419,10 +419,86 @@ def extras(raws, device):
     grid.cleanup()
     cs.cleanup()
     out["ringless_pt2pl"] = ringless_leg(device)
+    e2e = odometry_leg(raws, device)
+    if e2e is not None:
+        out["odometry_e2e"] = e2e
     out["voxel_sweep"] = {"what": "configs[2]: %d synthetic LiDAR-like points (10 sweeps): Voxelizer.addPoints per sweep, Morton radix "
                                   "sort + cell table of the whole cloud, exact NN of the cloud jittered by 5 cm" % len(cloud),
                           "rows": rows}
     return out
+
+
+def odometry_leg(raws, device):
+    """The reference's real unit of work, a driver frame (EnvironmentConstructor.calculateTransition_imu :154-265: place by
+    the IMU, refine against the block's reference cloud, pose, apply, voxelize, replace the reference every 10th frame),
+    over the thirty real sweeps with their OXTS records: as one stream of device work (pcp_chain_*) and, beside it, frame
+    by frame through EnvironmentConstructor on the host with the same kernels underneath."""
+    imu_file = os.path.join(GOLD, "ref_imu.npz")
+    if not os.path.exists(imu_file) or len(raws) < 30:
+        return None
+    from pointcloudprocessing_amd import EnvironmentConstructor, Voxelizer
+    from pointcloudprocessing_amd.chain import OdometryChain, imu_rows
+    from pointcloudprocessing_amd.oxts import OxtsDataReader, parse_timestamp
+    g = np.load(imu_file)
+    rd = OxtsDataReader()
+    for k, (vals, stamp) in enumerate(zip(g["oxts_values"], g["oxts_stamps"])):
+        rd.add_record(f"{k:010d}", vals, parse_timestamp(str(stamp)))
+    rd.finish()
+    records = [rd.getOx(k) for k in rd.getfilenames()[:len(raws)]]
+    rows, rots, steps, _ = imu_rows(records)
+    F = len(raws)
+    pinned = PinnedFrames(raws)
+    cs = ComputeShader(maxPointsPerCloud=200000, maxScans=100, device=device)
+    chain = OdometryChain(max_frames=F, max_points=1 << 17, device=device)
+    walls, devs, track, voxels = [], [], None, 0
+    for rep in range(6):
+        chain.reset()
+        vox = Voxelizer(cs, None)
+        vox.separate_colors, vox.filter_outliers = False, False
+        vox.init(0.5)
+        cs.synchronize()
+        c0 = time.perf_counter()
+        track = chain.collect(chain.submit(pinned, rows, point_to_plane=True, iterations=MAX_ITER, tol=TOL, voxelizer=vox))
+        walls.append(time.perf_counter() - c0)
+        devs.append(chain.last_chain_ms)
+        voxels = vox.stored_voxels
+        vox.cleanup()
+    chain.close()
+    pinned.close()
+    # the same drive frame by frame on the host
+    reader = lidar.LidarDataReader(device=device)
+    for k, raw in enumerate(raws):
+        reader.add_frame(f"{k:010d}", raw)
+    icp = PointcloudIcpContainer(cs)
+    env = EnvironmentConstructor(None, rd, reader, icp, cs, voxelizer=Voxelizer(cs, None))
+    host = []
+    for rep in range(3):
+        env.init(0.5)
+        c0 = time.perf_counter()
+        for _ in range(F):
+            frame, rec = env.getNextFrameData(0)
+            env.calculateTransition_imu(frame, rec, point_to_plane=True, iterations=MAX_ITER)
+        cs.synchronize()
+        host.append(time.perf_counter() - c0)
+    same = all(np.array_equal(track[k][1], env.prev_poses[k][1]) for k in range(F))
+    path = float(np.linalg.norm(track[-1][1]))
+    env.cleanup()
+    reader.cleanup()
+    cs.cleanup()
+    if not same and not os.environ.get("PCP_BENCH_NOCHECK"):
+        raise SystemExit("INVALID: the device chain and the frame-by-frame driver disagree on the refined positions")
+    wall = float(np.median(walls[1:]))
+    return {"what": "the %d real sweeps as one drive: IMU placement, point-to-plane refinement against the block's reference cloud "
+                    "(<= 10 iterations, 15 full ones when a block closes), pose, refined cloud, Voxelizer feed at 0.5 m, reference "
+                    "replaced every 10th frame; raw bytes in page-locked host memory in, every frame's pose and position out, map "
+                    "on the device" % F,
+            "frames_per_s": F / wall, "ms_per_frame": wall / F * 1e3, "device_ms_per_frame": float(np.median(devs[1:])) / F,
+            "frames_per_s_best": F / min(walls[1:]), "voxels": int(voxels), "path_m": path,
+            "iterations_per_frame": float(np.mean([len(t[4]) for t in track[1:]])),
+            "host_driven": {"what": "EnvironmentConstructor.calculateTransition_imu per frame (decoded clouds on the host, NumPy "
+                                    "placement and pose algebra, device loop, Voxelizer.addPoints from host arrays)",
+                            "frames_per_s": F / float(np.median(host[1:])), "ms_per_frame": float(np.median(host[1:])) / F * 1e3},
+            "same_positions_as_host_driven": bool(same)}
 
 
 def ringless_leg(device):

@@ -933,7 +933,7 @@ k_map_finish(const FinishArgs F, int solve, int mode, int max_iter, float tol, i
 // The host half of one iteration from an already summed (all-reduced) 8x8 tile.
 __global__ void k_map_pose(const float* __restrict__ tile, IcpState* __restrict__ st, float* __restrict__ hb_trace,
                            float* __restrict__ dx_trace, int mode, int max_iter, float tol, int full_iter) {
-    if (threadIdx.x != 0 || st->done) return;
+    if (threadIdx.x >= 64 || st->done) return;       // one wave: pose_step spreads the step's trigonometry over its lanes
     const int it = st->iter;
     float v[PCP_NVAL];
 #pragma unroll
@@ -942,7 +942,7 @@ __global__ void k_map_pose(const float* __restrict__ tile, IcpState* __restrict_
         for (int c = r; c < 6; ++c) v[tri(r, c)] = tile[r * 8 + c];
         v[21 + r] = tile[r * 8 + 6];
     }
-    for (int k = 0; k < 64; ++k) hb_trace[(size_t)it * 64 + k] = tile[k];
+    hb_trace[(size_t)it * 64 + threadIdx.x] = tile[threadIdx.x];
     pose_step(v, st, dx_trace, it, mode, max_iter, tol, full_iter);
 }
 

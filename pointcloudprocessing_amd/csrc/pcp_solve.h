@@ -85,12 +85,33 @@ __device__ __forceinline__ void rotation_xyz(float xr, float yr, float zr, doubl
     mm3(M, Rz, R);
 }
 
+// rotation_xyz with its six trigonometric values taken from the first six lanes of the calling wave (lane j < 3: cos of
+// angle j, lane 3 + j: sin of angle j; float64 evaluation rounded to float32, as above): the evaluations, which are most
+// of a step's serial time on one lane, run side by side.  Every lane of the wave must call it; all get the same matrix.
+__device__ __forceinline__ void rotation_xyz_wave(const float xr, const float yr, const float zr, double* R) {
+    const int lane = threadIdx.x & 63;
+    const float ang = (lane % 3 == 0) ? xr : ((lane % 3 == 1) ? yr : zr);
+    const double a = (double)ang;
+    const float mine = (lane < 3) ? (float)cos(a) : (float)sin(a);
+    const double cx = (double)__shfl(mine, 0, 64), cy = (double)__shfl(mine, 1, 64), cz = (double)__shfl(mine, 2, 64);
+    const double sx = (double)__shfl(mine, 3, 64), sy = (double)__shfl(mine, 4, 64), sz = (double)__shfl(mine, 5, 64);
+    const double Rz[9] = {cz, -sz, 0, sz, cz, 0, 0, 0, 1.0};
+    const double Ry[9] = {cy, 0, sy, 0, 1.0, 0, -sy, 0, cy};
+    const double Rx[9] = {1.0, 0, 0, 0, cx, -sx, 0, sx, cx};
+    double M[9];
+    mm3(Rx, Ry, M);
+    mm3(M, Rz, R);
+}
+
 // The host half of one iteration, dispatchPointToPoint / dispatchPointToPlane
 // (PointcloudIcpContainer.py:24-29, :47-69), from the 27 summed values: solve in
 // float64, round dx to float32, convergence test, rotation for the next step.
 __device__ __forceinline__ void pose_step(const float (&v)[PCP_NVAL], IcpState* __restrict__ st,
                                           float* __restrict__ dx_out, const int it, const int mode,
                                           const int max_iter, const float tol, const int full_iter) {
+    // Called by every lane of one wave with the same values: the solve runs redundantly in all lanes (no lane waits
+    // for another), the rotation's trigonometry is spread over six of them, lane 0 stores.
+    const bool writer = (threadIdx.x & 63) == 0;
     double H[6][6], rhs[6], x[6];
 #pragma unroll
     for (int r = 0; r < 6; ++r) {
@@ -99,28 +120,39 @@ __device__ __forceinline__ void pose_step(const float (&v)[PCP_NVAL], IcpState* 
         rhs[r] = -(double)v[21 + r];
     }
     if (!solve6(H, rhs, x)) {
-        st->singular = 1;
-        st->done = 1;
-        st->pending = 0;
-        st->iter = it + 1;
+        if (writer) {
+            st->singular = 1;
+            st->done = 1;
+            st->pending = 0;
+            st->iter = it + 1;
+        }
         return;
     }
     float dx[6];
 #pragma unroll
-    for (int k = 0; k < 6; ++k) { dx[k] = (float)x[k]; dx_out[(size_t)it * 6 + k] = dx[k]; }
-    st->iter = it + 1;
+    for (int k = 0; k < 6; ++k) {
+        dx[k] = (float)x[k];
+        if (writer) dx_out[(size_t)it * 6 + k] = dx[k];
+    }
+    if (writer) st->iter = it + 1;
     if (mode == PCP_MODE_PLANE && !full_iter) {
         float s = 0.0f;                       // np.mean(np.abs(delta_x)), float32
 #pragma unroll
         for (int k = 0; k < 6; ++k) s = s + fabsf(dx[k]);
         if (s / 6.0f < tol) {
-            st->converged = 1;
-            st->done = 1;
-            st->pending = 0;
+            if (writer) {
+                st->converged = 1;
+                st->done = 1;
+                st->pending = 0;
+            }
             return;
         }
     }
-    rotation_xyz(dx[3], dx[4], dx[5], st->R);
+    double R[9];
+    rotation_xyz_wave(dx[3], dx[4], dx[5], R);
+    if (!writer) return;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) st->R[k] = R[k];
     st->t[0] = (double)dx[0]; st->t[1] = (double)dx[1]; st->t[2] = (double)dx[2];
     st->pending = 1;
     if (it + 1 >= max_iter) st->done = 1;
@@ -201,10 +233,12 @@ __device__ __forceinline__ double grid_axis10(const int k) {
 // t_opt = mean' - R_opt mean.  One block of PCP_POSE_THREADS threads; thread 0 leaves t_opt in out[0..3), R_opt (row-major)
 // in out[3..12), out[12] = 1 when W was rank-deficient.  `applied` steps of 6 float32 (t, then the angles) are read from dx.
 #define PCP_POSE_THREADS 256
+#define PCP_POSE_CHUNK 32         // steps whose rotations are prepared together (6 threads per step)
 __device__ inline void pose_from_steps(const float* __restrict__ dx, const int applied, double* __restrict__ out) {
     __shared__ double s_red[PCP_POSE_THREADS / 64][12];
     __shared__ double s_mean[6];
-    __shared__ double s_Rt[12];
+    __shared__ double s_Rt[PCP_POSE_CHUNK][12];
+    __shared__ double s_trig[PCP_POSE_CHUNK][6];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     constexpr int PER = (1000 + PCP_POSE_THREADS - 1) / PCP_POSE_THREADS;
     double g0[PER][3], g[PER][3];
@@ -215,20 +249,40 @@ __device__ inline void pose_from_steps(const float* __restrict__ dx, const int a
         g0[j][0] = grid_axis10(ii / 100); g0[j][1] = grid_axis10((ii / 10) % 10); g0[j][2] = grid_axis10(ii % 10);
         g[j][0] = g0[j][0]; g[j][1] = g0[j][1]; g[j][2] = g0[j][2];
     }
-    for (int s = 0; s < applied; ++s) {
+    // the steps' rotations, PCP_POSE_CHUNK at a time: thread 6 s + j takes trigonometric value j of step s (cos of the
+    // three angles, then their sines), thread s then multiplies the three axis rotations out (rotation_xyz's products)
+    for (int base = 0; base < applied; base += PCP_POSE_CHUNK) {
+        const int chunk = min(applied - base, PCP_POSE_CHUNK);
         __syncthreads();
-        if (tid == 0) {
-            const float* d = dx + (size_t)s * 6;
-            rotation_xyz(d[3], d[4], d[5], s_Rt);
-            s_Rt[9] = (double)d[0]; s_Rt[10] = (double)d[1]; s_Rt[11] = (double)d[2];
+        if (tid < 6 * chunk) {
+            const int s = tid / 6, j = tid % 6;
+            const double a = (double)dx[(size_t)(base + s) * 6 + 3 + j % 3];
+            s_trig[s][j] = (double)((j < 3) ? (float)cos(a) : (float)sin(a));
         }
         __syncthreads();
+        if (tid < chunk) {
+            const double cx = s_trig[tid][0], cy = s_trig[tid][1], cz = s_trig[tid][2];
+            const double sx = s_trig[tid][3], sy = s_trig[tid][4], sz = s_trig[tid][5];
+            const double Rz[9] = {cz, -sz, 0, sz, cz, 0, 0, 0, 1.0};
+            const double Ry[9] = {cy, 0, sy, 0, 1.0, 0, -sy, 0, cy};
+            const double Rx[9] = {1.0, 0, 0, 0, cx, -sx, 0, sx, cx};
+            double M[9], R[9];
+            mm3(Rx, Ry, M);
+            mm3(M, Rz, R);
+            const float* d = dx + (size_t)(base + tid) * 6;
+            for (int k = 0; k < 9; ++k) s_Rt[tid][k] = R[k];
+            s_Rt[tid][9] = (double)d[0]; s_Rt[tid][10] = (double)d[1]; s_Rt[tid][11] = (double)d[2];
+        }
+        __syncthreads();
+        for (int s = 0; s < chunk; ++s) {
+            const double* Rt = s_Rt[s];
 #pragma unroll
-        for (int j = 0; j < PER; ++j) {
-            const double x = g[j][0], y = g[j][1], z = g[j][2];
-            g[j][0] = ((s_Rt[0] * x + s_Rt[1] * y) + s_Rt[2] * z) + s_Rt[9];
-            g[j][1] = ((s_Rt[3] * x + s_Rt[4] * y) + s_Rt[5] * z) + s_Rt[10];
-            g[j][2] = ((s_Rt[6] * x + s_Rt[7] * y) + s_Rt[8] * z) + s_Rt[11];
+            for (int j = 0; j < PER; ++j) {
+                const double x = g[j][0], y = g[j][1], z = g[j][2];
+                g[j][0] = ((Rt[0] * x + Rt[1] * y) + Rt[2] * z) + Rt[9];
+                g[j][1] = ((Rt[3] * x + Rt[4] * y) + Rt[5] * z) + Rt[10];
+                g[j][2] = ((Rt[6] * x + Rt[7] * y) + Rt[8] * z) + Rt[11];
+            }
         }
     }
     // block sums in a fixed order: a thread's own points, the wave's butterfly, the waves one after the other
@@ -353,21 +407,21 @@ __device__ __forceinline__ void finish_body(const FinishArgs& F, const int solve
         float* tmp = out; out = other; other = tmp;
         n = groups;
     }
-    if (threadIdx.x != 0) return;
+    if (threadIdx.x >= 64) return;            // the first wave finishes: every lane holds the 27 sums
     const int it = solve ? st->iter : 0;
     float v[PCP_NVAL];
 #pragma unroll
     for (int k = 0; k < PCP_NVAL; ++k) v[k] = in[k];
-    float* hb = hb_out + (size_t)it * 64;
+    {   // the summed tile as the reference reads it back (8 x 8, rows 6-7 and column 7 zero): element `lane`
+        const int r = lane >> 3, c = lane & 7;
+        float val = 0.0f;
 #pragma unroll
-    for (int r = 0; r < 8; ++r)
+        for (int rr = 0; rr < 6; ++rr)
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            float val = 0.0f;
-            if (r < 6 && c < 6) val = v[r <= c ? tri(r, c) : tri(c, r)];
-            else if (r < 6 && c == 6) val = v[21 + r];
-            hb[r * 8 + c] = val;
-        }
+            for (int cc = 0; cc < 7; ++cc)
+                if (rr == r && cc == c) val = (cc < 6) ? v[rr <= cc ? tri(rr, cc) : tri(cc, rr)] : v[21 + rr];
+        hb_out[(size_t)it * 64 + lane] = val;
+    }
     if (!solve) return;
     pose_step(v, st, dx_out, it, mode, max_iter, tol, full_iter);
 }
