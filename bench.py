@@ -544,16 +544,30 @@ def scan_to_map_leg(raws, rank, world, device, dist, exchange):
     a card) the tile goes through torch.distributed instead."""
     import torch
     from pointcloudprocessing_amd.scan_to_map import MODE_POINT, MapRegistration, RcclComm
+    from pointcloudprocessing_amd.cell_grid import partition_keys
     a, b = lidar.frame_from_raw(raws[0][:, :3]), lidar.frame_from_raw(raws[1][:, :3])
     sweeps = 100 * world
     step = np.array([0.02, 0.0, -0.33])
-    map_pts = np.concatenate([a + k * step for k in range(sweeps)])
     k = sweeps // 2
     scan = b + (k + 1) * step + np.array([0.04, 0.0, 0.05])
     comm = RcclComm(rank, world, device) if exchange == "rccl" else None
     c0 = time.perf_counter()
-    reg = MapRegistration(map_pts, 0.5, nn_cell=0.15, rank=rank, world=world, device=device, comm=comm)
+    # The key ranges are cut once, by rank 0, from a sample of the map (every 8th sweep: balance is all the cuts decide)
+    # and handed to the others -- world + 1 keys instead of every rank sorting the whole map; each rank then takes its
+    # share of the map chunk by chunk (MapRegistration.ingest keeps the points in or next to its range), so no rank
+    # ever holds more than one chunk of the whole map in host memory.
+    box = [None]
+    if rank == 0:
+        sample = np.concatenate([a + j * step for j in range(0, sweeps, 8)])
+        box[0] = partition_keys(sample, 0.5, world, device)
+    dist.broadcast_object_list(box, src=0)
+    chunk = 25
+    reg = MapRegistration(np.concatenate([a + j * step for j in range(chunk)]), 0.5, nn_cell=0.15, rank=rank, world=world,
+                          device=device, comm=comm, ranges=box[0])
+    for c in range(chunk, sweeps, chunk):
+        reg.ingest(np.concatenate([a + j * step for j in range(c, min(sweeps, c + chunk))]))
     build_s = time.perf_counter() - c0
+    map_points = sweeps * len(a)
     times, res = [], None
     for _ in range(6):
         torch.cuda.synchronize()
@@ -571,10 +585,10 @@ def scan_to_map_leg(raws, rank, world, device, dist, exchange):
         comm.close()
     return {"what": "configs[4]: %d-point map (%d sweeps) split over %d ranks by partition-cell key range, %d-point scan, "
                     "point-to-point, 10 iterations, exact neighbours within 0.4 m; per iteration one all-reduce of the 8x8 tile"
-                    % (len(map_pts), sweeps, world, len(scan)),
+                    % (map_points, sweeps, world, len(scan)),
             "exchange": "RCCL inside the library (pcp_grid_icp_run_comm)" if comm is not None else "torch.distributed over gloo (rehearsal)",
             "ms_per_registration": float(np.median(times[1:]) * 1e3), "build_and_partition_s": build_s,
-            "slab_points_per_rank": slabs, "iterations": int(len(res[2])), "all_ranks_hold_the_same_steps": bool(same),
+            "map_points": int(map_points), "slab_points_per_rank": slabs, "iterations": int(len(res[2])), "all_ranks_hold_the_same_steps": bool(same),
             "translation": [float(v) for v in res[0]]}
 
 

@@ -463,6 +463,9 @@ int pcp_comm_unique_id(char* id128);
 /* Collective: every rank of the world calls it with the same id (ncclCommInitRank). */
 int pcp_comm_init(int device, int world, int rank, const char* id128, pcp_comm** out);
 int pcp_comm_destroy(pcp_comm* comm);
+/* Tears the communicator down without waiting for collectives in flight (ncclCommAbort): what a rank calls after a
+ * failure, so that its peers' pending all-reduces end with an error instead of waiting for it. */
+int pcp_comm_abort(pcp_comm* comm);
 int pcp_comm_info(pcp_comm* comm, int* world, int* rank);
 /* In-place sum of 64 floats in device memory over all ranks, enqueued on hip_stream. */
 int pcp_comm_allreduce_tile(pcp_comm* comm, float* tile_dev, void* hip_stream);
@@ -471,7 +474,9 @@ int pcp_grid_allreduce_tile(pcp_grid* grid, pcp_comm* comm, float* tile_dev);
 /* pcp_grid_icp_run for a map split over the ranks of comm: every rank holds its share of the map
  * (pcp_grid_build_slab), its key range (pcp_grid_set_owned_keys) and the whole scan as working copy
  * (pcp_grid_source); per iteration partial tile -> all-reduce -> solve, every rank solving the same
- * system; all ranks return the same steps.  With a world of 1 the result equals pcp_grid_icp_run. */
+ * system; all ranks return the same steps.  With a world of 1 the result equals pcp_grid_icp_run.  When the call fails
+ * on one rank, that rank's caller must abort the communicator (pcp_comm_abort), which releases the peers still
+ * waiting in an all-reduce with an error instead of leaving them there. */
 int pcp_grid_icp_run_comm(pcp_grid* grid, pcp_comm* comm, int mode, double radius, int max_iter, float tol,
                           int full_iter, float* dx_trace, float* hb_trace, int* iters, int* converged);
 

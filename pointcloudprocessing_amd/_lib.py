@@ -108,6 +108,7 @@ SIGNATURES = {
     "pcp_comm_unique_id": (C.c_int, [C.c_char_p]),
     "pcp_comm_init": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_char_p, C.POINTER(C.c_void_p)]),
     "pcp_comm_destroy": (C.c_int, [C.c_void_p]),
+    "pcp_comm_abort": (C.c_int, [C.c_void_p]),
     "pcp_comm_info": (C.c_int, [C.c_void_p, _i32p, _i32p]),
     "pcp_comm_allreduce_tile": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "pcp_grid_allreduce_tile": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -97,6 +97,9 @@ class ComputeShader:
         lines = np.ascontiguousarray(scan_lines4, dtype=np.uint32)
         o4 = np.resize(origin, (4,)).astype(np.float32)
         check(self._lib.pcp_set_target(self._ctx, f32p(a4), len(a4), u32p(lines), len(lines), f32p(o4)))
+        # pcp_set_target only enqueues the copy of the points: the padded array has to outlive it, i.e. stay referenced
+        # until the next upload replaces it (every call that returns results waits for the stream in between)
+        self._target_keep = a4
 
     # ------------------------------------------------------------------ point to point
     def prepareLS(self, points_a, scan_lines, points_b, origin, debug_mode=False):

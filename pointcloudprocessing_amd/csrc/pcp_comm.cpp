@@ -24,6 +24,7 @@ struct Rccl {
     ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;          // optional
     ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
 };
@@ -51,6 +52,7 @@ int bind_rccl() {
     r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(h, "ncclGetUniqueId");
     r.CommInitRank = (decltype(r.CommInitRank))dlsym(h, "ncclCommInitRank");
     r.CommDestroy = (decltype(r.CommDestroy))dlsym(h, "ncclCommDestroy");
+    r.CommAbort = (decltype(r.CommAbort))dlsym(h, "ncclCommAbort");
     r.AllReduce = (decltype(r.AllReduce))dlsym(h, "ncclAllReduce");
     r.GetErrorString = (decltype(r.GetErrorString))dlsym(h, "ncclGetErrorString");
     if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllReduce || !r.GetErrorString)
@@ -111,6 +113,14 @@ int pcp_comm_destroy(pcp_comm* c) {
     if (!c) return 0;
     (void)hipSetDevice(c->device);
     if (c->comm) (void)g_rccl.CommDestroy(c->comm);
+    delete c;
+    return 0;
+}
+
+int pcp_comm_abort(pcp_comm* c) {
+    if (!c) return 0;
+    (void)hipSetDevice(c->device);
+    if (c->comm) (void)(g_rccl.CommAbort ? g_rccl.CommAbort(c->comm) : g_rccl.CommDestroy(c->comm));
     delete c;
     return 0;
 }

@@ -2015,7 +2015,11 @@ int pcp_grid_icp_run_comm(pcp_grid* g, pcp_comm* comm, int mode, double radius, 
     if (pcp_grid_icp_reset(g)) return 1;
     // Every rank enqueues the same max_iter exchanges: the summed tile, hence the solved step and the
     // convergence flag, are identical on all ranks, and once a rank's loop is done its launches return at
-    // once while the (256-byte) all-reduces keep the ranks in step.
+    // once while the (256-byte) all-reduces keep the ranks in step.  The partial tile is rewritten from the rank's
+    // level-1 sums before every exchange (k_map_finish with solve = 0 does not look at the done flag), so the
+    // exchanges behind the loop's end sum the same partial tiles again and again: nothing accumulates in it.
+    // A rank that fails in here leaves its peers inside their next all-reduce: the caller of a failed rank has to
+    // abort the communicator (pcp_comm_abort), which releases them with an error.
     for (int it = 0; it < max_iter; ++it) {
         if (pcp_grid_ls_dev(g, mode, radius, g->comm_tile)) return 1;
         if (pcp_comm_allreduce_tile(comm, g->comm_tile, (void*)g->stream)) return 1;

@@ -239,6 +239,11 @@ __global__ void __launch_bounds__(64) k_seq_describe(const SeqDescribe D) {
     }
 }
 
+__global__ void k_seq_origin(LsArgs* __restrict__ ls, PrepArgs* __restrict__ prep, int n_pairs, float4 o) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < n_pairs) { ls[p].o = o; prep[p].o = o; }
+}
+
 // What the host wants back per pair, gathered into one array so that a single copy fetches a whole run.
 struct SeqRecord {
     int iters, converged, singular, flags, n_a, n_b, n_lines, pad;
@@ -478,14 +483,17 @@ int pcp_seq_submit_placed(pcp_seq* s, const float* const* raw_xyzi, const int* n
     // origin as uploaded: np.resize(origin, (4,)) repeats, [ox, oy, oz, ox] (ComputeShader.py:436-437); it sits in the
     // descriptors' value half, which the host owns: refreshed only when it changes
     const float4 o4 = make_float4((float)origin3[0], (float)origin3[1], (float)origin3[2], (float)origin3[0]);
+    bool stale = false;
     for (int p = 0; p < P; ++p) {
         pcp_ctx* c = s->ctxs[p];
         if (memcmp(&c->origin, &o4, sizeof(float4)) != 0) {
             c->origin = o4;
-            PCP_CHECK(hipMemcpyAsync((char*)(s->ls_dev + p) + offsetof(LsArgs, o), &c->origin, sizeof(float4), hipMemcpyHostToDevice, q));
-            PCP_CHECK(hipMemcpyAsync((char*)(s->prep_dev + p) + offsetof(PrepArgs, o), &c->origin, sizeof(float4), hipMemcpyHostToDevice, q));
+            stale = true;
         }
     }
+    // the value travels as a kernel argument (copied when the launch is made), not as an asynchronous copy out of host
+    // memory that a later submission may overwrite
+    if (stale) hipLaunchKernelGGL(k_seq_origin, dim3(cdiv(P, 64)), dim3(64), 0, q, s->ls_dev, s->prep_dev, P, o4);
     // the kernel half of preparePointPlane / prepareLS for all pairs
     const size_t sm = (size_t)s->max_scans * (sizeof(int2) + sizeof(float4));
     hipLaunchKernelGGL(k_unit_batch, dim3(cdiv(s->max_points, 256), P), dim3(256), 0, q, s->prep_dev);

@@ -104,6 +104,13 @@ class RcclComm:
             self._lib.pcp_comm_destroy(self._comm)
             self._comm = None
 
+    def abort(self):
+        """After a failed call on this rank: ends the communicator without waiting, so that peers blocked in an
+        all-reduce are released with an error (pcp_comm_abort)."""
+        if self._comm:
+            self._lib.pcp_comm_abort(self._comm)
+            self._comm = None
+
     def __del__(self):
         try:
             self.close()
@@ -200,9 +207,13 @@ class HipMapBackend:
         dx = np.zeros((max_iter, 6), dtype=np.float32)
         hb = np.zeros((max_iter, 8, 8), dtype=np.float32)
         it, cv = C.c_int(0), C.c_int(0)
-        self._check(self._lib.pcp_grid_icp_run_comm(self.grid._g, comm._comm, int(mode), float(radius), int(max_iter),
-                                                    float(tol), 1 if full_iter else 0, f32p(dx), f32p(hb),
-                                                    C.byref(it), C.byref(cv)))
+        try:
+            self._check(self._lib.pcp_grid_icp_run_comm(self.grid._g, comm._comm, int(mode), float(radius), int(max_iter),
+                                                        float(tol), 1 if full_iter else 0, f32p(dx), f32p(hb),
+                                                        C.byref(it), C.byref(cv)))
+        except Exception:
+            comm.abort()        # peers still inside an all-reduce are released with an error instead of waiting for this rank
+            raise
         return dx[:it.value], bool(cv.value), hb[:it.value]
 
     def fetch(self, max_iter):
@@ -231,12 +242,15 @@ class MapRegistration:
     CPU checker); group: a torch.distributed process group, None = the default one when world > 1."""
 
     def __init__(self, map_points, cell, normals=None, rank=0, world=1, device=0, backend=None, group=None,
-                 nn_cell=None, comm=None):
+                 nn_cell=None, comm=None, ranges=None):
         """cell: edge of the partition cells (ownership and halo; the search radius may not exceed it).
         nn_cell: edge of the search grid's cells on each rank (default: cell); dense maps want it
         smaller, a few point spacings.
         comm: an RcclComm -- the exchange step then runs inside the library (pcp_grid_icp_run_comm /
-        pcp_grid_allreduce_tile) instead of through torch.distributed."""
+        pcp_grid_allreduce_tile) instead of through torch.distributed.
+        ranges: the ranks' key ranges [(lo, hi)] when they have been fixed elsewhere (e.g. cut by one rank from a sample
+        of the map and broadcast, partition_cuts()): map_points then only needs to hold what this rank is to start
+        with, the rest of the map arrives through ingest()."""
         self.rank, self.world, self.cell = int(rank), int(world), float(cell)
         self.group = group
         self.comm = comm
@@ -246,7 +260,12 @@ class MapRegistration:
         pts = np.asarray(map_points, dtype=np.float64)[:, :3]
         on_device = hasattr(self.backend, "partition")
         # the NumPy statement of the partition rule serves backends without a device (the CPU tests)
-        self.ranges = self.backend.partition(pts, cell, self.world) if on_device else split_key_space(pts, cell, self.world)
+        if ranges is not None:
+            self.ranges = [(int(lo), int(hi)) for lo, hi in ranges]
+            if len(self.ranges) != self.world:
+                raise ValueError("one key range per rank")
+        else:
+            self.ranges = self.backend.partition(pts, cell, self.world) if on_device else split_key_space(pts, cell, self.world)
         lo, hi = self.ranges[self.rank]
         if self.world > 1 and on_device:
             self.backend.build(pts, normals, self.cell, nn_cell, slab=(lo, hi))

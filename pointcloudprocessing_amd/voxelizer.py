@@ -112,6 +112,13 @@ class Voxelizer:
                                    "its statistics can no longer be fetched")
             self.compute.readVoxelStatistics(self._voxel_stats)
             self._stats_stale = False
+        if (self._voxel_stats is not None and getattr(self, "inited", False)
+                and getattr(self.compute, "resident_statistics", False)):
+            # the device copy is the authority: an in-place edit of the mirror would be lost silently, so the mirror is
+            # handed out read-only (assigning a whole array to voxel_stats makes the host copy the authority again)
+            view = self._voxel_stats.view()
+            view.flags.writeable = False
+            return view
         return self._voxel_stats
 
     @voxel_stats.setter
@@ -268,6 +275,9 @@ class Voxelizer:
         """One stager dispatch (:116-119, :141-152) -> the staged rows.  With the statistics resident on the device the
         host array only tells the dispatch how many rows there are."""
         resident = bool(getattr(self.compute, "resident_statistics", False))
+        if resident and getattr(self.compute, "voxel_map_epoch", None) != self._map_epoch:
+            raise RuntimeError("the device's voxel map has been replaced (another Voxelizer took this ComputeShader): "
+                               "this map can no longer be staged from its resident statistics")
         stats = self._voxel_stats if resident else self.voxel_stats
         out, rows = self.compute.prepareDispatchVoxelStager(
             self._voxel_index, self.stored_voxels, self.max_points, stats,
