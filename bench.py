@@ -355,7 +355,9 @@ def extras(raws, device):
         "roofline": {"bound": "hbm", "kernel": "k_nn (hinted; one launch = one pair, so latency- not bandwidth-limited)",
                      "achieved": nn_bytes / hk / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": nn_bytes / hk / 1e9 / HBM_PEAK_GBS, "traffic": None},
-        "note": "call = host buffers in, results on the host (2 MB upload + 1.5 MB read-back, PCIe inclusive)",
+        "note": "call = the reader's float64 cloud in host memory in, indices and distances in host arrays out (cast + pad "
+                "through a page-locked buffer in chunks, 2 MB up, 1.5 MB down, PCIe inclusive); the PCIe transfers alone are "
+                "about 65 us of a call",
     }
 
     # --- configs[0]: consecutive pair, voxelize + NN + point-to-point ICP x 20

@@ -80,6 +80,17 @@ int pcp_normals(pcp_ctx* ctx, float* out_normals /* n_a x 4 */);
 int pcp_nn(pcp_ctx* ctx, const float* b_xyzw, int n_b,
            uint32_t* idx, float* dist2, float* hint_out);
 
+/* pcp_nn / pcp_ls_point / pcp_ls_plane for a source cloud as the caller holds it -- layout PCP_PTS_F64_XYZ (n rows of 3
+ * float64, what PointcloudIcpContainer hands to dispatchNNS / dispatchLS / dispatchPointPlane, ComputeShader.py:747, :517,
+ * :587), PCP_PTS_F64_ROWS, PCP_PTS_F32_XYZ or PCP_PTS_F32_XYZW (constants below) -- without the caller's pad_points pass (:956-961): the
+ * rows are cast and padded chunk by chunk into a page-locked buffer of the context, each chunk uploaded while the next
+ * is converted.  pcp_nn_staged leaves its results in page-locked arrays of the context (corr_out of the reference,
+ * :231-241, is backend-owned in the same way): *idx, *dist2 and *hint (hint may be NULL) point at n_b entries that
+ * stay valid until the next pcp_nn_staged call on the context.  pcp_ls_staged: mode PCP_MODE_POINT / PCP_MODE_PLANE. */
+int pcp_nn_staged(pcp_ctx* ctx, const void* pts, int layout, int n_b, const uint32_t** idx, const float** dist2,
+                  const float** hint);
+int pcp_ls_staged(pcp_ctx* ctx, const void* pts, int layout, int n_b, int mode, int debug, float* hb /* 64 */);
+
 /* Device time (ms, HIP events on the context's stream) of the search kernels of the last pcp_nn call,
  * without its upload and read-back. */
 int pcp_nn_kernel_ms(pcp_ctx* ctx, float* ms);
@@ -262,6 +273,8 @@ int pcp_voxel_staged_points(pcp_ctx* ctx, const double** xyz_dev, size_t* n_poin
 #define PCP_PTS_F32_XYZ 3
 #define PCP_PTS_F32_ROWS (-3)
 #define PCP_PTS_F64_XYZ 8
+#define PCP_PTS_F64_ROWS (-8) /* three coordinate rows of n float64 (x row, y row, z row): a transposed (3, n) cloud such as
+                                 (R @ points.T).T of LidarDataReader.py:66-67 as it lies in memory; pcp_nn_staged / pcp_ls_staged only */
 typedef struct pcp_voxel_frame {
     int serial;          /* ticket */
     int stored_before;   /* voxels in the table when the frame arrived */

@@ -43,6 +43,8 @@ SIGNATURES = {
     "pcp_reset_hints": (C.c_int, [_ctx]),
     "pcp_normals": (C.c_int, [_ctx, _f32p]),
     "pcp_nn": (C.c_int, [_ctx, _f32p, C.c_int, _u32p, _f32p, _f32p]),
+    "pcp_nn_staged": (C.c_int, [_ctx, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
+    "pcp_ls_staged": (C.c_int, [_ctx, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, _f32p]),
     "pcp_nn_kernel_ms": (C.c_int, [_ctx, _f32p]),
     "pcp_ls_point": (C.c_int, [_ctx, _f32p, C.c_int, C.c_int, _f32p]),
     "pcp_ls_plane": (C.c_int, [_ctx, _f32p, C.c_int, _f32p]),

@@ -111,13 +111,42 @@ class ComputeShader:
         self.saveUniformInfo(points_a, points_b, origin, padded, debug_mode)
         self._active = "ls"
 
+    @staticmethod
+    def _source_layout(points):
+        """(layout code of include/pcp.h, address) when the library can take the array as it lies -- float64 (n, 3),
+        float32 (n, 3) or (n, 4), C-contiguous -- so that no padded float32 copy (pad_points, :956-961) is made on the
+        host first; None otherwise."""
+        a = points
+        if (isinstance(a, np.ndarray) and a.ndim == 2 and a.dtype == np.float64 and a.shape[1] == 3 and len(a) > 1
+                and a.T.flags.c_contiguous and not a.flags.c_contiguous):
+            return ComputeShader.PTS_F64_ROWS, a.T.ctypes.data      # a transposed cloud: its three coordinate rows as they lie
+        if not (isinstance(a, np.ndarray) and a.ndim == 2 and a.flags.c_contiguous and len(a)):
+            return None
+        if a.dtype == np.float64 and a.shape[1] == 3:
+            return ComputeShader.PTS_F64_XYZ, a.ctypes.data
+        if a.dtype == np.float32 and a.shape[1] == 3:
+            return ComputeShader.PTS_F32_XYZ, a.ctypes.data
+        if a.dtype == np.float32 and a.shape[1] == 4:
+            return ComputeShader.PTS_F32_XYZW, a.ctypes.data
+        return None
+
+    def _dispatch_ls(self, points_b, mode, debug):
+        hb = np.zeros((8, 8), dtype=np.float32)
+        lay = self._source_layout(points_b)
+        if lay is not None:
+            check(self._lib.pcp_ls_staged(self._ctx, C.c_void_p(lay[1]), lay[0], len(points_b), mode, debug, f32p(hb)))
+        else:
+            b4 = self.pad_points(points_b)
+            if mode == MODE_POINT:
+                check(self._lib.pcp_ls_point(self._ctx, f32p(b4), len(b4), debug, f32p(hb)))
+            else:
+                check(self._lib.pcp_ls_plane(self._ctx, f32p(b4), len(b4), f32p(hb)))
+        return hb[:6, :6], hb[:, 6][:6]
+
     def dispatchLS(self, points_b):
         """:517-529 -> (H (6,6) float32, b (6,) float32)."""
-        b4 = self.pad_points(points_b)
-        hb = np.zeros((8, 8), dtype=np.float32)
         debug = int(self.debug_info is not None and self.debug_info[0] >= 1.0)
-        check(self._lib.pcp_ls_point(self._ctx, f32p(b4), len(b4), debug, f32p(hb)))
-        return hb[:6, :6], hb[:, 6][:6]
+        return self._dispatch_ls(points_b, MODE_POINT, debug)
 
     # ------------------------------------------------------------------ normals / point to plane
     def prepareDispatchNormals(self, points_a, scan_lines, origin, read=True):
@@ -167,10 +196,7 @@ class ComputeShader:
 
     def dispatchPointPlane(self, points_b):
         """:587-608 -> (H, b)."""
-        b4 = self.pad_points(points_b)
-        hb = np.zeros((8, 8), dtype=np.float32)
-        check(self._lib.pcp_ls_plane(self._ctx, f32p(b4), len(b4), f32p(hb)))
-        return hb[:6, :6], hb[:, 6][:6]
+        return self._dispatch_ls(points_b, MODE_PLANE, 0)
 
     # ------------------------------------------------------------------ stand-alone NN
     def prepareNNS(self, points_a, scan_lines, points_b, origin):
@@ -183,6 +209,20 @@ class ComputeShader:
     def dispatchNNS(self, points_b):
         """:747-759 -> (idx uint32[N_b], dist2 float32[N_b]); corr_out holds
         (idx as float, dist2, 0, ring) like the reference's read-back."""
+        lay = self._source_layout(points_b)
+        if lay is not None:
+            # the cloud goes up as it lies (cast and padded through the context's page-locked buffer), the results come
+            # down into page-locked arrays of the context; corr_out is put together from them when somebody reads it
+            n = len(points_b)
+            pi, pd, ph = C.c_void_p(), C.c_void_p(), C.c_void_p()
+            check(self._lib.pcp_nn_staged(self._ctx, C.c_void_p(lay[1]), lay[0], n, C.byref(pi), C.byref(pd), C.byref(ph)))
+            views = (np.ctypeslib.as_array((C.c_uint32 * n).from_address(pi.value)),
+                     np.ctypeslib.as_array((C.c_float * n).from_address(pd.value)),
+                     np.ctypeslib.as_array((C.c_float * n).from_address(ph.value)))
+            idx, dist = views[0].copy(), views[1].copy()          # the caller's own arrays, as the reference's astype gives
+            self._corr_parts = (idx, dist, views[2])              # the hints stay where they are until corr_out is looked at
+            self.lens_data = np.array([self.lens_data[0], n, self.lens_data[2], 0]).astype(np.uint32)
+            return idx, dist
         b4 = self.pad_points(points_b)
         n = len(b4)
         idx = np.empty(n, dtype=np.uint32)
@@ -190,14 +230,33 @@ class ComputeShader:
         hint = np.empty(n, dtype=np.float32)
         check(self._lib.pcp_nn(self._ctx, f32p(b4), n, u32p(idx), f32p(dist), f32p(hint)))
         self.lens_data = np.array([self.lens_data[0], n, self.lens_data[2], 0]).astype(np.uint32)
-        self.reallocate_out(self.lens_data)
-        self.corr_out[:, 0] = idx
-        self.corr_out[:, 1] = dist
-        self.corr_out[:, 2] = 0
-        self.corr_out[:, 3] = hint
+        self._corr_parts = (idx, dist, hint)
         # the reference returns corr_out[:, 0].astype(uint32), corr_out[:, 1].astype(float32): indices below 2^24
         # survive the float32 column unchanged, so these are the same arrays without two strided passes
         return idx, dist
+
+    @property
+    def corr_out(self):
+        """(N_b, 4) float32: index as float, squared distance, 0, ring -- the reference's read-back of its correspondence
+        buffer (:756-759), a backend-owned array reused by the next call; assembled when it is looked at."""
+        parts = getattr(self, "_corr_parts", None)
+        if parts is not None:
+            idx, dist, hint = parts
+            self._corr_parts = None
+            n = len(idx)
+            if self._corr_out is None or len(self._corr_out) != n:
+                self._corr_out = np.zeros((n, 4), dtype=np.float32)
+                self.prev_out_b = n
+            self._corr_out[:, 0] = idx
+            self._corr_out[:, 1] = dist
+            self._corr_out[:, 2] = 0
+            self._corr_out[:, 3] = hint
+        return self._corr_out
+
+    @corr_out.setter
+    def corr_out(self, value):
+        self._corr_out = value
+        self._corr_parts = None
 
     # ------------------------------------------------------------------ hierarchical sum
     def hbSum(self, tiles):
@@ -300,7 +359,7 @@ class ComputeShader:
         self.resident_statistics = False        # a Voxelizer that reads its statistics lazily switches this on
 
     # -- a whole frame of Voxelizer.addPoints as one enqueue and one wait (pcp_voxel_add*)
-    PTS_F32_XYZW, PTS_F32_XYZ, PTS_F32_ROWS, PTS_F64_XYZ = 4, 3, -3, 8
+    PTS_F32_XYZW, PTS_F32_XYZ, PTS_F32_ROWS, PTS_F64_XYZ, PTS_F64_ROWS = 4, 3, -3, 8, -8
 
     def voxelAddFrame(self, points, voxel_size, stored_voxel_num, begin_index, max_points, filter_outliers,
                       max_staging=1024, device_ptr=None, n_points=None, layout=None, after_stream=None):

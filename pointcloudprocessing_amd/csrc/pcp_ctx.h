@@ -27,11 +27,16 @@ struct pcp_ctx {
     hipStream_t own_stream = nullptr, stream = nullptr;
     float4 *a = nullptr, *ua = nullptr, *normals = nullptr, *b32 = nullptr;
     double *b_in = nullptr, *b64 = nullptr;
-    float *hint = nullptr, *nn_dist = nullptr;
-    uint32_t* nn_idx = nullptr;
+    float* hint = nullptr;
+    uint32_t* nn_idx = nullptr;        // 2 max_points words: the indices of the last search, its squared distances behind them
     int2* scan = nullptr;
     int2* scan_host = nullptr;     // page-locked staging of the scan-line table (max_scans rows)
     hipEvent_t scan_copied = nullptr;   // recorded behind the copy out of scan_host
+    // page-locked staging of the stepwise calls (made on first use): the source cloud on its way up, and the
+    // correspondence buffer (index, squared distance, ring hint per point) on its way down
+    float4* stage_in = nullptr;
+    uint32_t* stage_idx = nullptr;     // indices, squared distances behind them
+    float* stage_hint = nullptr;
     struct pcp_batch* batch = nullptr;  // the batch that has adopted this context, if any
     float4* ring_stat = nullptr;   // per ring: (sin, cos) of lowest and highest elevation
     float4* ring_bins = nullptr;   // the same per ring and azimuth bin (PCP_AZ_BINS per ring)

@@ -682,6 +682,42 @@ int upload_b32(pcp_ctx* c, const float* b_xyzw, int n_b) {
     return 0;
 }
 
+// The source cloud of a stepwise call from the caller's (pageable) array into b32 -- the float32 rows of 4 that
+// ComputeShader.pad_points (:956-961) makes -- through a page-locked buffer of the context: the rows are converted /
+// padded chunk by chunk on the host and every finished chunk is on its way up while the next one is converted, instead
+// of one blocking copy out of pageable memory behind a full NumPy pass.  The casts are C's float64 -> float32
+// conversions (round to nearest even, NumPy's astype).
+int stage_source(pcp_ctx* c, const void* pts, int layout, int n_b) {
+    if (!c->have_target) return pcp_fail("no target: call pcp_set_target first");
+    if (!pts) return pcp_fail("null source points");
+    if (n_b < 1 || n_b > c->max_points) return pcp_fail("n_b = %d outside [1, %d]", n_b, c->max_points);
+    if (layout != PCP_PTS_F32_XYZW && layout != PCP_PTS_F32_XYZ && layout != PCP_PTS_F64_XYZ && layout != PCP_PTS_F64_ROWS)
+        return pcp_fail("unknown point layout %d", layout);
+    if (!c->stage_in) PCP_CHECK(hipHostMalloc((void**)&c->stage_in, (size_t)c->max_points * sizeof(float4)));
+    c->n_b = n_b;
+    const int chunk = 32768;
+    for (int first = 0; first < n_b; first += chunk) {
+        const int m = (n_b - first < chunk) ? n_b - first : chunk;
+        float4* dst = c->stage_in + first;
+        if (layout == PCP_PTS_F32_XYZW) {
+            memcpy(dst, (const float4*)pts + first, (size_t)m * sizeof(float4));
+        } else if (layout == PCP_PTS_F32_XYZ) {
+            const float* src = (const float*)pts + 3 * (size_t)first;
+            for (int i = 0; i < m; ++i) dst[i] = make_float4(src[3 * i], src[3 * i + 1], src[3 * i + 2], 0.0f);
+        } else if (layout == PCP_PTS_F64_ROWS) {       // three coordinate rows of n_b: a transposed (3, n) cloud as it lies
+            const double* x = (const double*)pts + first;
+            const double* y = x + n_b;
+            const double* z = y + n_b;
+            for (int i = 0; i < m; ++i) dst[i] = make_float4((float)x[i], (float)y[i], (float)z[i], 0.0f);
+        } else {
+            const double* src = (const double*)pts + 3 * (size_t)first;
+            for (int i = 0; i < m; ++i) dst[i] = make_float4((float)src[3 * i], (float)src[3 * i + 1], (float)src[3 * i + 2], 0.0f);
+        }
+        PCP_CHECK(hipMemcpyAsync(c->b32 + first, dst, (size_t)m * sizeof(float4), hipMemcpyHostToDevice, c->stream));
+    }
+    return 0;
+}
+
 LsArgs ls_args(const pcp_ctx* c, int debug, float* tiles) {
     LsArgs A;
     memset(&A, 0, sizeof(A));          // padding bytes too: descriptors are compared with memcmp
@@ -770,9 +806,11 @@ int launch_ls_quad(pcp_ctx* c, int mode) {
     return 0;
 }
 
-int ls_stepwise(pcp_ctx* c, const float* b_xyzw, int n_b, int mode, int debug, float* hb, float* tiles_host) {
+int ls_stepwise(pcp_ctx* c, const void* pts, int layout, int n_b, int mode, int debug, float* hb, float* tiles_host) {
     if (int e = use(c)) return e;
-    if (int e = upload_b32(c, b_xyzw, n_b)) return e;
+    if (layout == 0) {                      // the caller's padded float32 rows, copied as they are
+        if (int e = upload_b32(c, (const float*)pts, n_b)) return e;
+    } else if (int e = stage_source(c, pts, layout, n_b)) return e;
     float* tiles = nullptr;
     if (tiles_host) {
         if (int e = ensure_tiles(c)) return e;
@@ -836,8 +874,7 @@ int pcp_create(int device, int max_points, int max_scans, pcp_ctx** out) {
     A((void**)&c->b_in, n * 3 * sizeof(double));
     A((void**)&c->b64, n * 3 * sizeof(double));
     A((void**)&c->hint, n * sizeof(float));
-    A((void**)&c->nn_dist, n * sizeof(float));
-    A((void**)&c->nn_idx, n * sizeof(uint32_t));
+    A((void**)&c->nn_idx, 2 * n * sizeof(uint32_t));      // indices, and behind them the squared distances (one copy fetches both)
     A((void**)&c->scan, (size_t)max_scans * sizeof(int2));
     A((void**)&c->ring_stat, (size_t)max_scans * sizeof(float4));
     A((void**)&c->ring_bins, (size_t)max_scans * PCP_AZ_BINS * sizeof(float4));
@@ -873,13 +910,15 @@ int pcp_destroy(pcp_ctx* c) {
         batch_forget(c->batch, c);
     }
     if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
-    void* bufs[] = {c->a, c->ua, c->normals, c->b32, c->b_in, c->b64, c->hint, c->nn_dist, c->nn_idx, c->scan, c->ring_stat, c->ring_bins,
+    void* bufs[] = {c->a, c->ua, c->normals, c->b32, c->b_in, c->b64, c->hint, c->nn_idx, c->scan, c->ring_stat, c->ring_bins,
                     c->partials, c->lvl0, c->lvl1, c->hb_trace, c->dx_trace, c->state, c->pose, c->pose_steps, c->tiles, c->tiles2};
     for (void* p : bufs)
         if (p) (void)hipFree(p);
     if (c->vox) pcp_voxel_state_free(c->vox);
     for (hipEvent_t ev : c->prof_events) (void)hipEventDestroy(ev);
     if (c->scan_host) (void)hipHostFree(c->scan_host);
+    for (void* p : {(void*)c->stage_in, (void*)c->stage_idx, (void*)c->stage_hint})
+        if (p) (void)hipHostFree(p);
     if (c->scan_copied) (void)hipEventDestroy(c->scan_copied);
     if (c->nn_ev0) (void)hipEventDestroy(c->nn_ev0);
     if (c->nn_ev1) (void)hipEventDestroy(c->nn_ev1);
@@ -1000,16 +1039,52 @@ int pcp_nn(pcp_ctx* c, const float* b_xyzw, int n_b, uint32_t* idx, float* dist2
     PCP_CHECK(hipEventRecord(c->nn_ev0, c->stream));
     if (int e = launch_first_rings<false>(c)) return e;          // queries still without a hint: their ring, found by 8 lanes each
     hipLaunchKernelGGL(k_nn, dim3(cdiv(n_b, PCP_BLOCK)), dim3(PCP_BLOCK), scan_smem(c), c->stream, c->a, c->ua, c->scan, c->ring_stat, c->ring_bins,
-                       c->n_a, c->n_scans, c->n_scans_search, c->origin, c->b32, n_b, c->hint, c->nn_idx, c->nn_dist);
+                       c->n_a, c->n_scans, c->n_scans_search, c->origin, c->b32, n_b, c->hint, c->nn_idx, (float*)(c->nn_idx + n_b));
     PCP_CHECK(hipGetLastError());
     PCP_CHECK(hipEventRecord(c->nn_ev1, c->stream));
     c->nn_timed = true;
     PCP_CHECK(hipMemcpyAsync(idx, c->nn_idx, (size_t)n_b * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-    PCP_CHECK(hipMemcpyAsync(dist2, c->nn_dist, (size_t)n_b * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    PCP_CHECK(hipMemcpyAsync(dist2, c->nn_idx + n_b, (size_t)n_b * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     if (hint_out)
         PCP_CHECK(hipMemcpyAsync(hint_out, c->hint, (size_t)n_b * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     PCP_CHECK(hipStreamSynchronize(c->stream));
     return 0;
+}
+
+int pcp_nn_staged(pcp_ctx* c, const void* pts, int layout, int n_b, const uint32_t** idx, const float** dist2, const float** hint) {
+    if (int e = use(c)) return e;
+    if (!idx || !dist2) return pcp_fail("null output");
+    if (int e = stage_source(c, pts, layout, n_b)) return e;
+    if (!c->stage_idx) {
+        PCP_CHECK(hipHostMalloc((void**)&c->stage_idx, 2 * (size_t)c->max_points * sizeof(uint32_t)));
+        PCP_CHECK(hipHostMalloc((void**)&c->stage_hint, (size_t)c->max_points * sizeof(float)));
+    }
+    if (!c->nn_ev0) {
+        PCP_CHECK(hipEventCreate(&c->nn_ev0));
+        PCP_CHECK(hipEventCreate(&c->nn_ev1));
+    }
+    PCP_CHECK(hipEventRecord(c->nn_ev0, c->stream));
+    if (int e = launch_first_rings<false>(c)) return e;
+    hipLaunchKernelGGL(k_nn, dim3(cdiv(n_b, PCP_BLOCK)), dim3(PCP_BLOCK), scan_smem(c), c->stream, c->a, c->ua, c->scan, c->ring_stat, c->ring_bins,
+                       c->n_a, c->n_scans, c->n_scans_search, c->origin, c->b32, n_b, c->hint, c->nn_idx, (float*)(c->nn_idx + n_b));
+    PCP_CHECK(hipGetLastError());
+    PCP_CHECK(hipEventRecord(c->nn_ev1, c->stream));
+    c->nn_timed = true;
+    // indices and distances lie behind one another on both sides: one copy
+    PCP_CHECK(hipMemcpyAsync(c->stage_idx, c->nn_idx, 2 * (size_t)n_b * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    if (hint) PCP_CHECK(hipMemcpyAsync(c->stage_hint, c->hint, (size_t)n_b * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    PCP_CHECK(hipStreamSynchronize(c->stream));
+    *idx = c->stage_idx;
+    *dist2 = (const float*)(c->stage_idx + n_b);
+    if (hint) *hint = c->stage_hint;
+    return 0;
+}
+
+int pcp_ls_staged(pcp_ctx* c, const void* pts, int layout, int n_b, int mode, int debug, float* hb) {
+    if (!hb) return pcp_fail("null output");
+    if (layout != PCP_PTS_F32_XYZW && layout != PCP_PTS_F32_XYZ && layout != PCP_PTS_F64_XYZ && layout != PCP_PTS_F64_ROWS)
+        return pcp_fail("unknown point layout %d", layout);
+    return ls_stepwise(c, pts, layout, n_b, mode, debug, hb, nullptr);
 }
 
 int pcp_nn_kernel_ms(pcp_ctx* c, float* ms) {
@@ -1023,17 +1098,17 @@ int pcp_nn_kernel_ms(pcp_ctx* c, float* ms) {
 
 int pcp_ls_point(pcp_ctx* c, const float* b_xyzw, int n_b, int debug, float* hb) {
     if (!hb) return pcp_fail("null output");
-    return ls_stepwise(c, b_xyzw, n_b, PCP_MODE_POINT, debug, hb, nullptr);
+    return ls_stepwise(c, b_xyzw, 0, n_b, PCP_MODE_POINT, debug, hb, nullptr);
 }
 
 int pcp_ls_plane(pcp_ctx* c, const float* b_xyzw, int n_b, float* hb) {
     if (!hb) return pcp_fail("null output");
-    return ls_stepwise(c, b_xyzw, n_b, PCP_MODE_PLANE, 0, hb, nullptr);
+    return ls_stepwise(c, b_xyzw, 0, n_b, PCP_MODE_PLANE, 0, hb, nullptr);
 }
 
 int pcp_ls_tiles(pcp_ctx* c, const float* b_xyzw, int n_b, int mode, int debug, float* tiles) {
     if (!tiles) return pcp_fail("null output");
-    return ls_stepwise(c, b_xyzw, n_b, mode, debug, nullptr, tiles);
+    return ls_stepwise(c, b_xyzw, 0, n_b, mode, debug, nullptr, tiles);
 }
 
 // ComputeShader.py:682-707: levels ping-pong between two buffers until one block is left.
