@@ -393,6 +393,36 @@ def extras(raws, device):
     rng = np.random.default_rng(1)
     q = cloud + rng.normal(0, 0.05, cloud.shape)
     cs = ComputeShader(maxPointsPerCloud=200000, device=device)
+    from pointcloudprocessing_amd import _lib as L
+    from pointcloudprocessing_amd.frame import DeviceFrame
+    dev_sweeps = []
+    for c in sweeps:                       # the same sweeps resident in device memory (float64 rows of 3), for the device-fed leg
+        f = DeviceFrame(max_points=200000, device=device)
+        f.upload(np.ascontiguousarray(c))
+        dev_sweeps.append(f)
+
+    def fed_from_device(size):
+        """Every sweep enqueued from device memory (pcp_voxel_add_dev: float32 cast, dispatch, stager, creation of the new
+        voxels), four frames in flight, the device's own voxel count carried from frame to frame."""
+        v = Voxelizer(cs, None)
+        v.init(size)
+        rec, tickets, begin = L.VoxelFrame(), [], 0
+        c0 = time.perf_counter()
+        for k, f in enumerate(dev_sweeps):
+            ptr, n = f.points_dev()
+            t = C.c_int(-1)
+            check(cs._lib.pcp_voxel_add_dev(cs._ctx, C.c_void_p(ptr), 8, n, float(size), 0 if not tickets else -1, begin, 1024, 0, 1024,
+                                            None, C.byref(t)))
+            tickets.append(t.value)
+            begin += n
+            if k >= 4:
+                check(cs._lib.pcp_voxel_add_wait(cs._ctx, tickets[k - 4], C.byref(rec)))
+        for t in tickets[-4:]:
+            check(cs._lib.pcp_voxel_add_wait(cs._ctx, t, C.byref(rec)))
+        dt = time.perf_counter() - c0
+        v.cleanup()
+        return dt, rec.stored
+
     grid, rows = None, []
     for size in (0.1, 0.2, 0.5, 1.0, 2.0):
         best = None
@@ -407,6 +437,9 @@ def extras(raws, device):
             stored = v.stored_voxels
             v.cleanup()
             best = dt if best is None else min(best, dt)
+        fed = min(fed_from_device(size) for _ in range(3))
+        if fed[1] != stored and not os.environ.get("PCP_BENCH_NOCHECK"):
+            raise SystemExit("INVALID: device-fed and host-fed voxel maps differ (%d / %d voxels)" % (fed[1], stored))
         if grid is None:
             grid = CellGrid(cloud, cell=size, device=device)
         else:
@@ -414,11 +447,34 @@ def extras(raws, device):
         info = grid.info()
         grid.query(q)
         qms = min(grid.query(return_kernel_ms=True)[2] for _ in range(3))
+        def roof(bytes_, seconds, kernel, why):
+            gbs = bytes_ / seconds / 1e9 if seconds else 0.0
+            return {"bound": "hbm", "kernel": kernel, "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                    "traffic": None, "limited_by": why}
+
+        sort_s, build_s = info["sort_ms"] * 1e-3, info["build_ms"] * 1e-3
         rows.append({"voxel_m": size, "voxels": int(stored), "voxelize_ms": best * 1e3, "voxelize_mpts_per_s": len(cloud) / best / 1e6,
+                     "voxelize_device_fed_ms": fed[0] * 1e3, "voxelize_device_fed_mpts_per_s": len(cloud) / fed[0] / 1e6,
                      "cells": int(info["cells"]), "morton_sort_ms": float(info["sort_ms"]), "sort_passes": int(info["sort_passes"]),
-                     "sort_gb_per_s": 24.0 * len(cloud) * info["sort_passes"] / (info["sort_ms"] * 1e-3) / 1e9 if info["sort_ms"] else None,
-                     "grid_build_ms": float(info["build_ms"]), "nn_ms": float(qms), "nn_queries_per_s": len(q) / (qms * 1e-3)})
+                     "sort_gb_per_s": 24.0 * len(cloud) * info["sort_passes"] / sort_s / 1e9 if sort_s else None,
+                     "grid_build_ms": float(info["build_ms"]), "nn_ms": float(qms), "nn_queries_per_s": len(q) / (qms * 1e-3),
+                     "roofline": {
+                         "voxelize": roof(28.0 * len(cloud) + 16.0 * stored, fed[0], "the frame feed (k_feed_voxelize, k_voxel_stage, radix "
+                                          "sort of the unknown points, k_feed_new_voxels, k_feed_shift_old: 26 launches per sweep)",
+                                          "launch latency: 10 sweeps of 100 k points, each a chain of 26 small dependent kernels "
+                                          "(profiles/r03_voxel_kernel_stats.csv); 28 B per point + 16 B per voxel is what the feed must move"),
+                         "morton_sort": roof(24.0 * len(cloud) * info["sort_passes"], sort_s, "k_rsd_hist / k_rsd_scan / k_rsd_scatter per "
+                                             "8-bit digit", "1 M keys: a pass is 3 launches of a few microseconds each; the scatter's 128-B runs "
+                                             "hold a pass at 2.3 TB/s at 50 M keys (profiles/r01_grid_50m.txt)"),
+                         "cell_table": roof(12.0 * len(cloud) + 16.0 * info["cells"], max(build_s - sort_s, 1e-9), "key / head / table kernels "
+                                            "of the grid build", "launch latency at 1 M points (a dozen small kernels around the sort)"),
+                         "grid_nn": roof(40.0 * len(q), qms * 1e-3, "k_grid_nn (exact neighbour over the 27 cells around a query)",
+                                         "gathers from the cells' point runs (L2-served): %d points per occupied cell at this size"
+                                         % max(1, len(cloud) // max(1, int(info["cells"])))),
+                     }})
     grid.cleanup()
+    for f in dev_sweeps:
+        f.cleanup()
     cs.cleanup()
     out["ringless_pt2pl"] = ringless_leg(device)
     e2e = odometry_leg(raws, device)
@@ -639,6 +695,76 @@ def run_leg_in_children(rank, dist, exchange, seconds):
     return {"error": "child exit code %d: %s" % (done.returncode, " | ".join(tail)[-400:])}
 
 
+def cpu_baseline_child(workload, pair):
+    """`bench.py --leg cpu-baseline --pair k`: one frame pair of the headline workload through the NumPy restatement (the
+    checker under oracle/), single-threaded, in a process of its own; prints its seconds."""
+    from oracle import np_oracle as O
+    raws, _ = real_frames()
+    i = pair % (len(raws) - 1)
+    c0 = time.perf_counter()
+    fa, fb = lidar.frame_from_raw(raws[i][:, :3]), lidar.frame_from_raw(raws[i + 1][:, :3])
+    if workload == "moved-copy":
+        fb = moved_copy(fa, i + 1)[0]
+    O.full_pt2pl(fa, fb, np.zeros(3), iterations=MAX_ITER)
+    print("PCP_CPU %.6f" % (time.perf_counter() - c0), flush=True)
+
+
+def cpu_baseline_all_cores(workload, n_frames):
+    """The same algorithm on the host's cores: one frame pair per worker process (decode, scan lines, normals, loop, pose in
+    NumPy, one thread each), as many workers as this box's share of cores (16 at most), all at once; value = pairs over the
+    wall time of the whole batch."""
+    import subprocess
+    workers = max(1, min(16, os.cpu_count() or 1, n_frames - 1))
+    env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
+    c0 = time.perf_counter()
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--leg", "cpu-baseline", "--pair", str(k), "--workload",
+                               workload], env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True) for k in range(workers)]
+    own = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=240)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            continue
+        for line in out.splitlines():
+            if line.startswith("PCP_CPU "):
+                own.append(float(line.split()[1]))
+    wall = time.perf_counter() - c0
+    if not own:
+        return None
+    return {"value": len(own) / wall, "unit": "frame-pairs/s", "cores": workers, "kind": "port",
+            "one_core_value": 1.0 / float(np.mean(own)),
+            "sample": "%d consecutive frame pairs of the same workload (decode, scan lines, normals, loop), NumPy restatement of "
+                      "the same algorithm, one single-threaded process per pair, all running at once: %.1f s of wall time, %.1f s "
+                      "per pair on its core; host reports %d logical cpus" % (len(own), wall, float(np.mean(own)), os.cpu_count() or 0)}
+
+
+def headline_roofline(res, achieved, args):
+    """The roofline object of the headline: achieved / peak / frac are the HBM figures (algorithmic bytes per launch over
+    the launch time measured by HIP events in this run); what the kernel is actually bound by is named from the committed
+    counter summaries of this workload (profiles/r*_issue_pipes.json, r*_traffic.json), not from a literal."""
+    pipes = issue_pipes(args.workload, args.pairs)
+    traffic = res["traffic"]
+    bound, why = "hbm", "no counter summary of this workload is committed: only the HBM fraction is known"
+    if pipes:
+        busiest = max((("texture-address units (gather issue)", pipes["ta_busy_avg"]), ("vector ALU", pipes["valu_busy"]),
+                       ("hbm", achieved / HBM_PEAK_GBS)), key=lambda kv: kv[1])
+        bound = busiest[0]
+        why = ("not HBM (%.1f %% of its peak): chains of dependent 16-byte gathers served by L1/L2. Counters of this workload (%s): "
+               "texture-address units %.0f %% busy on average and %.0f %% on the busiest, vector ALU %.0f %% busy, waves waiting %.0f %% "
+               "of their life, L2 hit rate %.0f %%"
+               % (100.0 * achieved / HBM_PEAK_GBS, pipes["source"].split(" (")[0], 100 * pipes["ta_busy_avg"], 100 * pipes["ta_busy_max"],
+                  100 * pipes["valu_busy"], 100 * pipes["waves_waiting"], 100 * pipes["l2_hit_rate"]))
+        if traffic and res["alg_bytes"]:
+            why += ("; `traffic` (L2 misses: every launch streams its float64 working copy, hints and each pair's target once) is "
+                    "%.1fx the algorithmic bytes, which count a target once per pair, not once per launch" % (traffic / res["alg_bytes"]))
+    return {"bound": bound, "kernel": res["kernel"], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+            "hbm_frac": achieved / HBM_PEAK_GBS, "binding_pipe_busy": (pipes or {}).get("ta_busy_avg"),
+            "avg_launch_us": res["avg_launch_s"] * 1e6, "launches_timed": res["ls_launches"],
+            "algorithmic_bytes_per_launch": res["alg_bytes"], "issue_pipes": pipes, "limited_by": why}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -649,12 +775,15 @@ def main():
     ap.add_argument("--workload", choices=("sequence", "sequence-imu", "moved-copy"), default="sequence")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
-    ap.add_argument("--leg", choices=("scan-to-map",), default=None, help=argparse.SUPPRESS)
+    ap.add_argument("--leg", choices=("scan-to-map", "cpu-baseline"), default=None, help=argparse.SUPPRESS)
+    ap.add_argument("--pair", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--no-latency", action="store_true",
                     help="skip the single-pair latency legs (profiling passes: every launch of the fused kernel then is a full step's)")
     args = ap.parse_args()
     if args.leg == "scan-to-map":
         return scan_to_map_child()
+    if args.leg == "cpu-baseline":
+        return cpu_baseline_child(args.workload, args.pair)
 
     import torch
     rank = int(os.environ.get("RANK", "0"))
@@ -706,18 +835,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_extras:
         more = extras(raws, device)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        from oracle import np_oracle as O
-        sample = [(0, 1), (1, 2)]
-        c0 = time.perf_counter()
-        for i, j in sample:
-            fa, fb = lidar.frame_from_raw(raws[i][:, :3]), lidar.frame_from_raw(raws[j][:, :3])
-            if args.workload == "moved-copy":
-                fb = moved_copy(fa, j)[0]
-            O.full_pt2pl(fa, fb, np.zeros(3), iterations=MAX_ITER)
-        cpu_s = time.perf_counter() - c0
-        cpu = {"value": len(sample) / cpu_s, "unit": "frame-pairs/s", "cores": 1, "kind": "port",
-               "sample": "%d frame pairs of the same workload (pairs 0->1 and 1->2: decode, scan lines, normals, loop), NumPy "
-                         "restatement of the same algorithm, single thread; host has %d logical cpus" % (len(sample), os.cpu_count() or 0)}
+        cpu = cpu_baseline_all_cores(args.workload, len(raws))
     if pinned is not None:
         pinned.close()
 
@@ -739,16 +857,7 @@ def main():
             "nn_queries_per_s": res["queries"] / elapsed,
             "config": {"workload": res["workload"], "pairs_per_gpu_per_step": args.pairs, "n_a": res["n_a"], "n_b": res["n_b"],
                        "iterations_per_pair": res["iters"], "parallelism": "independent pairs per GPU, batched launches"},
-            "roofline": {"bound": "hbm", "kernel": res["kernel"], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": res["traffic"],
-                         "avg_launch_us": res["avg_launch_s"] * 1e6, "launches_timed": res["ls_launches"],
-                         "algorithmic_bytes_per_launch": res["alg_bytes"],
-                         "issue_pipes": issue_pipes(args.workload, args.pairs),
-                         "limited_by": "not HBM: chains of dependent 16-byte gathers served by L1/L2. Counters of this workload "
-                                       "(profiles/r02_seq_pmc_*.csv): texture-address units 79 % busy on average and 91 % on the busiest, "
-                                       "vector ALU 73 % busy, waves waiting 72 % of their life, L2 hit rate 86 %; `traffic` (L2 misses: "
-                                       "every launch streams its float64 working copy, hints and each pair's target once) is 3x the "
-                                       "algorithmic bytes, which count a target once per pair, not once per launch"},
+            "roofline": headline_roofline(res, achieved, args),
             "cpu_baseline": cpu,
             "single_pair": single,
         }
