@@ -11,6 +11,7 @@ def means(path):
 
 
 sq, ta, l2 = means(sys.argv[1]), means(sys.argv[2]), means(sys.argv[3])
+tag = sys.argv[5] if len(sys.argv) > 5 else "r02"
 out = {"kernel": "k_ls_batch<1>", "workload": "sequence", "pairs_per_launch": 64,
        "valu_busy": sq["SQ_ACTIVE_INST_VALU"] * 4 / (sq["GRBM_GUI_ACTIVE"] / 8 * 1024),
        "ta_busy_avg": ta["TA_BUSY_avr"] / (ta["GRBM_GUI_ACTIVE"] / 8), "ta_busy_max": ta["TA_BUSY_max"] / (ta["GRBM_GUI_ACTIVE"] / 8),
@@ -20,6 +21,6 @@ out = {"kernel": "k_ls_batch<1>", "workload": "sequence", "pairs_per_launch": 64
        "vmem_read_instructions_per_wave": sq["SQ_INSTS_VMEM_RD"] / sq["SQ_WAVES"],
        "how": "vector ALU = SQ_ACTIVE_INST_VALU x 4 / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs); texture-address units = TA_BUSY / "
               "(GRBM_GUI_ACTIVE / 8); waiting = SQ_WAIT_ANY / SQ_WAVE_CYCLES",
-       "source": "profiles/r02_seq_pmc_sq.csv, r02_seq_pmc_ta.csv, r02_seq_pmc_l2.csv (separate rocprofv3 --pmc passes of bench.py's "
-                 "sequence workload, tools/profile_r02.sh)"}
+       "source": "profiles/%s_seq_pmc_sq.csv, %s_seq_pmc_ta.csv, %s_seq_pmc_l2.csv (separate rocprofv3 --pmc passes of bench.py's "
+                 "sequence workload, tools/profile_%s.sh)" % (tag, tag, tag, tag)}
 json.dump(out, open(sys.argv[4], "w"), indent=1)
