@@ -19,6 +19,9 @@
 // Instrumented build only (make stats): [0] ring visits by lanes, [1] ring passes executed by waves,
 // [2] wave searches, for hinted searches; [4..6] the same for searches over all rings.
 __device__ unsigned long long pcp_stats[8];
+// first_ring<K>: [0] waves, [1] loop rounds, [2] rounds in which some lane searched a ring, [3] ring searches by lanes,
+// [4] queries, [8 + r] waves that ran r searching rounds (r = 0..6, 7 = more)
+__device__ unsigned long long pcp_stats2[16];
 #endif
 
 namespace pcp {
@@ -396,6 +399,120 @@ __device__ __forceinline__ int find_closest(const Target& T, const float4 q, flo
     return glob;
 }
 
+// The all-rings search (hint -1) of find_closest for a wave in which NO lane has a hint, as dense passes.  In the
+// lock-step walk above a ring pass costs the wave the same whether one lane or all 64 need it, and beyond the first few
+// offsets only a few lanes do (a query far from every target point cannot rule rings out, its neighbours can).  Here the
+// wave walks the first PCP_POOL_LOCKSTEP offsets together as before; for the offsets behind them every lane only TESTS
+// its ring's bounds and puts the rings it cannot rule out on a list the wave shares (LDS; offset by offset and lane by
+// lane, so entries that lie together are neighbouring queries on the same or a neighbouring ring and their gathers
+// still fall into few lines).  Whenever 64 entries are waiting, the wave searches them in one pass, one entry per lane,
+// the query's point and direction fetched from the lane that owns it; the results meet in a per-query 64-bit word
+// (distance bits, ring, index) by an LDS minimum, which is the shader's order: smallest distance, then lowest ring.
+// The owners read their word back after every pass, so later bounds are tested against the tightened minimum.
+// A ring that is searched although the lock-step walk would have ruled it out by then can neither hold nor tie the
+// minimum, so the result is the same triple (point, ring, distance).  Needs Zs <= 256 and n_a <= 2^24.
+#ifndef PCP_POOL_LOCKSTEP
+#define PCP_POOL_LOCKSTEP 1
+#endif
+__device__ __forceinline__ unsigned long long pool_pack(const float d, const int ring, const int glob) {
+    return ((unsigned long long)__float_as_uint(d) << 32) | ((unsigned long long)(unsigned)ring << 24) | (unsigned long long)(unsigned)glob;
+}
+
+__device__ __forceinline__ int find_closest_pooled(const Target& T, const float4 q, const bool live, float& hint,
+                                                   unsigned long long* slot, unsigned short* items) {
+    const int lane = threadIdx.x & 63;
+    const float4 v = make_float4(q.x - T.o.x, (q.y - T.o.y) - PCP_LIDAR_OFF_Y, q.z - T.o.z, q.w - T.o.w);
+    const float rho2 = dot4(v, v);
+    const float len = sqrtf(rho2);
+    const float4 ref = make_float4(v.x / len, v.y / len, v.z / len, v.w / len);   // == unit_sphere(q, o)
+    const float sq = ref.y;
+    const float cq = sqrtf(ref.x * ref.x + ref.z * ref.z + ref.w * ref.w);
+    const bool can_prune = cq > 0.05f;
+    const gf4_t my_bins = T.bins + (size_t)az_bin(ref.x, ref.z) * T.Z;
+    const float far = (v.x * v.x + v.z * v.z) * PCP_AZ_FAR;
+    float mind = PCP_BIG;
+    int glob = 0, ring = -1;
+    const int from = 0, to = T.Zs;
+    int centre = 0;
+    if (can_prune) {
+        float lo = PCP_BIG;
+        for (int r = from; r < to; ++r) {
+            const float lb = ring_lower_bound(T.stat[r], sq, cq, rho2);
+            if (lb < lo) { lo = lb; centre = r; }
+        }
+    }
+    const int last = live ? 2 * max(centre - from, to - 1 - centre) : -1;
+    // ---- the first offsets in lock step, as find_closest walks them
+    for (int k = 0; k < PCP_POOL_LOCKSTEP; ++k) {
+        const int r = centre + ((k & 1) ? (k + 1) / 2 : -(k / 2));
+        if (k > last || r < from || r >= to) continue;
+        if (can_prune && mind < PCP_BIG) {
+            if (ring_lower_bound(T.stat[r], sq, cq, rho2) > mind) continue;
+            if (ring_bin_lower_bound(ld4(my_bins, r), sq, cq, rho2, far) > mind) continue;
+        }
+        const int2 se = T.scan[r];
+        int best;
+        float d;
+        ring_window<10, false>(T, q, ref, se.x, se.y, -1, best, d);
+        if (d < mind || (d == mind && ring >= 0 && r < ring)) { mind = d; glob = best; ring = r; }
+    }
+    // ---- the other offsets: listed, and searched 64 at a time
+    slot[lane] = (ring >= 0) ? pool_pack(mind, ring, glob) : ~0ull;
+    int kmax = last;
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) kmax = max(kmax, __shfl_xor(kmax, m, 64));
+    int count = 0;                                   // entries waiting (the same in every lane)
+    auto run_pass = [&](const int n_items) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        const bool act = lane < n_items;
+        const int item = act ? (int)items[lane] : 0;
+        const int l = item & 63, r = item >> 6;
+        const float4 oq = make_float4(__shfl(q.x, l, 64), __shfl(q.y, l, 64), __shfl(q.z, l, 64), __shfl(q.w, l, 64));
+        const float4 oref = make_float4(__shfl(ref.x, l, 64), __shfl(ref.y, l, 64), __shfl(ref.z, l, 64), __shfl(ref.w, l, 64));
+        if (act) {
+            const int2 se = T.scan[r];
+            int best;
+            float d;
+            ring_window<10, false>(T, oq, oref, se.x, se.y, -1, best, d);
+            if (d < PCP_BIG) atomicMin(&slot[l], pool_pack(d, r, best));
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        // entries behind the ones just searched move to the front
+        const int rest = count - n_items;
+        unsigned short keep = 0;
+        if (lane < rest) keep = items[n_items + lane];
+        __builtin_amdgcn_wave_barrier();
+        if (lane < rest) items[lane] = keep;
+        count = rest;
+        const unsigned long long mine = slot[lane];
+        if (mine != ~0ull) mind = fminf(mind, __uint_as_float((unsigned)(mine >> 32)));
+    };
+    for (int k = PCP_POOL_LOCKSTEP; k <= kmax; ++k) {
+        const int r = centre + ((k & 1) ? (k + 1) / 2 : -(k / 2));
+        bool want = k <= last && r >= from && r < to;
+        if (want && can_prune && mind < PCP_BIG) {
+            if (ring_lower_bound(T.stat[r], sq, cq, rho2) > mind) want = false;
+            else if (ring_bin_lower_bound(ld4(my_bins, r), sq, cq, rho2, far) > mind) want = false;
+        }
+        const unsigned long long b = __ballot(want);
+        if (b) {
+            if (want) items[count + __popcll(b & ((1ull << lane) - 1ull))] = (unsigned short)(lane | (r << 6));
+            count += __popcll(b);
+            if (count >= 64) run_pass(64);
+        }
+    }
+    if (count > 0) run_pass(count);
+    const unsigned long long mine = slot[lane];
+    if (mine != ~0ull) {
+        ring = (int)((mine >> 24) & 255ull);
+        glob = (int)(mine & 0xFFFFFFull);
+    }
+    if (ring >= 0) hint = (float)ring;
+    return glob;
+}
+
 // The all-rings search (hint -1) of find_closest with K lanes per query, K a power of two <= 64 and the
 // K lanes adjacent: lane `sub` takes the offsets k = sub, sub + K, ... of the same outward walk, the K
 // running minima are shared after every round (they only serve the bound tests, and a ring whose lower
@@ -432,6 +549,11 @@ __device__ __forceinline__ int first_ring(const Target& T, const bool live, cons
     const int last = live ? 2 * max(centre - from, to - 1 - centre) : -1;
     float mind = PCP_BIG, shared = PCP_BIG;
     int ring = -1;
+#ifdef PCP_STATS
+    int st_rounds = 0, st_active = 0;
+    const bool st_leader = __ffsll((long long)__ballot(true)) - 1 == (int)(threadIdx.x & 63);
+    if (st_leader) { atomicAdd(&pcp_stats2[0], 1ull); atomicAdd(&pcp_stats2[4], (unsigned long long)(__popcll(__ballot(live)) / K)); }
+#endif
     for (int k0 = 0; __any(k0 <= last); k0 += K) {
         const int k = k0 + sub;
         const int r = centre + ((k & 1) ? (k + 1) / 2 : -(k / 2));
@@ -440,6 +562,14 @@ __device__ __forceinline__ int first_ring(const Target& T, const bool live, cons
             if (ring_lower_bound(T.stat[r], sq, cq, rho2) > shared) visit = false;
             else if (ring_bin_lower_bound(ld4(my_bins, r), sq, cq, rho2, far) > shared) visit = false;
         }
+#ifdef PCP_STATS
+        {
+            const unsigned long long act = __ballot(visit);
+            ++st_rounds;
+            if (act) ++st_active;
+            if (st_leader) atomicAdd(&pcp_stats2[3], (unsigned long long)__popcll(act));
+        }
+#endif
         if (visit) {
             const int2 se = T.scan[r];
             int best;
@@ -451,6 +581,13 @@ __device__ __forceinline__ int first_ring(const Target& T, const bool live, cons
 #pragma unroll
         for (int s = 1; s < K; s <<= 1) shared = fminf(shared, __shfl_xor(shared, s, 64));
     }
+#ifdef PCP_STATS
+    if (st_leader) {
+        atomicAdd(&pcp_stats2[1], (unsigned long long)st_rounds);
+        atomicAdd(&pcp_stats2[2], (unsigned long long)st_active);
+        atomicAdd(&pcp_stats2[8 + (st_active < 7 ? st_active : 7)], 1ull);
+    }
+#endif
 #pragma unroll
     for (int s = 1; s < K; s <<= 1) {
         const float od = __shfl_xor(mind, s, 64);

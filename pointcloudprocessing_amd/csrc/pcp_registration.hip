@@ -279,7 +279,7 @@ struct LsArgs {
     int skip_store_iter;      // the dispatch (st->iter) whose moved points nobody will read: not written back (-1 = none)
 };
 
-template <int MODE, bool F64SRC>
+template <int MODE, bool F64SRC, bool POOL = false>
 __device__ __forceinline__ void ls_body(const LsArgs& A, char* smem, const unsigned block) {
     const float4* __restrict__ a = A.a;
     const float4* __restrict__ normals = A.normals;
@@ -326,8 +326,19 @@ __device__ __forceinline__ void ls_body(const LsArgs& A, char* smem, const unsig
     float d = 0.0f;
     if (!debug) {
         float h = in ? hint[i] : -1.0f;
+        bool pooled = false;
+        if (POOL) {
+            // a wave of a freshly prepared pair: nobody has a hint, the all-rings search runs as dense passes
+            __shared__ unsigned long long pool_slot[64];
+            __shared__ unsigned short pool_items[128];
+            if (__all(h == -1.0f) && T.Zs <= 256) {
+                pooled = true;
+                nn = find_closest_pooled(T, q, in, h, pool_slot, pool_items);
+                if (!in) nn = 0;
+            }
+        }
         if (in) {
-            nn = find_closest(T, q, h);
+            if (!pooled) nn = find_closest(T, q, h);
             hint[i] = h;
             d = distsq(q, ld4(T.a, nn));
         }
@@ -511,6 +522,21 @@ __global__ void __launch_bounds__(PCP_BLOCK) __attribute__((amdgpu_waves_per_eu(
     const LsArgs A = all[pair];
     if ((int)(block * PCP_BLOCK) >= A.n_b) return;
     ls_body<MODE, true>(A, smem, block);
+}
+
+// The first dispatch of freshly prepared pairs (no query has a hint yet): the same kernel with the all-rings search
+// of a wave run as dense passes (find_closest_pooled); a wave in which some lane has a hint searches as above.
+#ifndef PCP_LS_FIRST_WAVES
+#define PCP_LS_FIRST_WAVES 8
+#endif
+template <int MODE>
+__global__ void __launch_bounds__(PCP_BLOCK) __attribute__((amdgpu_waves_per_eu(PCP_LS_FIRST_WAVES, PCP_LS_FIRST_WAVES))) k_ls_batch_first(const LsArgs* __restrict__ all) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    unsigned pair, block;
+    pair_and_block(pair, block);
+    const LsArgs A = all[pair];
+    if ((int)(block * PCP_BLOCK) >= A.n_b) return;
+    ls_body<MODE, true, true>(A, smem, block);
 }
 
 
@@ -788,6 +814,11 @@ int launch_first_rings(pcp_ctx* c) {
     else hipLaunchKernelGGL((k_first_rings<32, F64SRC>), grid, block, sm, c->stream, A);
     PCP_CHECK(hipGetLastError());
     return 0;
+}
+
+bool use_pool() {      // PCP_LS_POOL=0: the first dispatch of a batch walks all rings in lock step like the later ones
+    static const bool pool = [] { const char* e = getenv("PCP_LS_POOL"); return !(e && e[0] == '0'); }();
+    return pool;
 }
 
 bool use_quad() {
@@ -1513,7 +1544,10 @@ int pcp_batch_icp_launch(pcp_batch* b, int mode, int max_iter, float tol, int fu
             }
             PCP_CHECK(hipEventRecord(b->prof_events[2 * it], b->stream));
         }
-        if (mode == PCP_MODE_POINT) hipLaunchKernelGGL((k_ls_batch<PCP_MODE_POINT>), grid, block, sm, b->stream, b->ls_dev);
+        if (it == 0 && use_pool()) {
+            if (mode == PCP_MODE_POINT) hipLaunchKernelGGL((k_ls_batch_first<PCP_MODE_POINT>), grid, block, sm, b->stream, b->ls_dev);
+            else hipLaunchKernelGGL((k_ls_batch_first<PCP_MODE_PLANE>), grid, block, sm, b->stream, b->ls_dev);
+        } else if (mode == PCP_MODE_POINT) hipLaunchKernelGGL((k_ls_batch<PCP_MODE_POINT>), grid, block, sm, b->stream, b->ls_dev);
         else hipLaunchKernelGGL((k_ls_batch<PCP_MODE_PLANE>), grid, block, sm, b->stream, b->ls_dev);
         PCP_CHECK(hipGetLastError());
         if (b->profile) {
@@ -1580,6 +1614,18 @@ int pcp_stats_read(unsigned long long* out8, int reset) {
     if (reset) {
         unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         PCP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(pcp_stats), z, 64));
+    }
+    return 0;
+}
+#endif
+
+#ifdef PCP_STATS
+int pcp_stats2_read(unsigned long long* out16, int reset) {
+    PCP_CHECK(hipDeviceSynchronize());
+    PCP_CHECK(hipMemcpyFromSymbol(out16, HIP_SYMBOL(pcp_stats2), 128));
+    if (reset) {
+        unsigned long long z[16] = {0};
+        PCP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(pcp_stats2), z, 128));
     }
     return 0;
 }
