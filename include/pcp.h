@@ -391,6 +391,13 @@ int pcp_grid_append_slab(pcp_grid* grid, const double* xyz, size_t n, const floa
 int pcp_grid_append_dev(pcp_grid* grid, const double* xyz_dev, size_t n, long long first_id);
 int pcp_grid_append_slab_dev(pcp_grid* grid, const double* xyz_dev, size_t n, double own_cell, unsigned long long lo,
                              unsigned long long hi, long long first_id, size_t* n_kept);
+/* Appends made between these two calls are collected -- coordinates and ids copied behind one another in device memory --
+ * and join the map at pcp_grid_collect_end in ONE sort, merge and cell table instead of one per batch: for a producer that
+ * hands over many small batches before anybody reads the map (the Voxelizer's final staging passes, Voxelizer.py:139-165:
+ * a thousand voxels per dispatch).  The map is the one the same appends would have left one by one.  While appends are
+ * being collected every call that reads or rebuilds the map fails; batches may not carry normals. */
+int pcp_grid_collect_begin(pcp_grid* grid);
+int pcp_grid_collect_end(pcp_grid* grid);
 /* Facts about the last build: points, occupied cells, extent in cells, radix
  * passes, device time of the whole build and of the sort alone (ms). Any pointer may be NULL. */
 int pcp_grid_info(pcp_grid* grid, unsigned long long* n_points, unsigned long long* n_cells, int* extent3,

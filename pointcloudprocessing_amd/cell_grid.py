@@ -87,6 +87,20 @@ class CellGrid:
         self.data = None                                    # the host copy of the first build no longer is the map
         return kept
 
+    def collect(self):
+        """Context manager: appends made inside it are collected on the device and join the map together when it ends
+        (pcp_grid_collect_begin / _end: one sort, merge and cell table for all of them); nothing may read the map meanwhile."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def _collect():
+            check(self._lib.pcp_grid_collect_begin(self._g))
+            try:
+                yield self
+            finally:
+                check(self._lib.pcp_grid_collect_end(self._g))
+        return _collect()
+
     def append_device(self, xyz_dev, n, first_id=None, slab=None):
         """append() for n points that already lie in this device's memory as n x 3 float64 (xyz_dev: address, e.g.
         from ComputeShader.stagedPointsDevice); whatever produced them must have completed."""

@@ -490,7 +490,7 @@ class ComputeShader:
         return unknown_points, debug_data
 
     def prepareDispatchVoxelStager(self, voxel_index, stored_voxel_num, max_points, voxel_statistics,
-                                   filter_outliers, stage_everything=False, max_staging=1024, debug=False):
+                                   filter_outliers, stage_everything=False, max_staging=1024, debug=False, fetch_rows=True):
         """:761-835.  voxel_index is not uploaded here (the reference's upload is
         commented out, :772-775): the table of the last bufferVoxelIndex /
         prepareDispatchVoxelizer call is used.  voxel_statistics is updated in place."""
@@ -501,10 +501,14 @@ class ComputeShader:
             raise PcpError("voxel_statistics must be a C-contiguous float32 array")
         counter = np.zeros((1, 16), dtype=np.int32)
         if self.resident_statistics:
-            # the statistics stay on the device (readVoxelStatistics fetches them); voxel_statistics only gives the row count
+            # the statistics stay on the device (readVoxelStatistics fetches them); voxel_statistics only gives the row count.
+            # fetch_rows=False (a caller that resolves the staged rows on the device): the rows stay there too, only their
+            # number comes back -- readStagedRows fetches them if somebody asks after all
             check(self._lib.pcp_voxel_stage_resident(self._ctx, len(voxel_statistics), int(stored_voxel_num), int(max_points),
                                                      int(bool(filter_outliers)), int(bool(stage_everything)), int(max_staging),
-                                                     i32p(counter), i32p(self.voxel_stage_out)))
+                                                     i32p(counter), i32p(self.voxel_stage_out) if fetch_rows else None))
+            if not fetch_rows and not debug:
+                return voxel_statistics, int(counter[0][0])
         else:
             check(self._lib.pcp_voxel_stage(self._ctx, f32p(voxel_statistics), len(voxel_statistics),
                                             int(stored_voxel_num), int(max_points), int(bool(filter_outliers)),

@@ -399,9 +399,10 @@ __device__ __forceinline__ int find_closest(const Target& T, const float4 q, flo
     return glob;
 }
 
-// The all-rings search (hint -1) of find_closest for a wave in which NO lane has a hint, as dense passes.  In the
-// lock-step walk above a ring pass costs the wave the same whether one lane or all 64 need it, and beyond the first few
-// offsets only a few lanes do (a query far from every target point cannot rule rings out, its neighbours can).  Here the
+// find_closest for a whole wave, with the ring searches behind the first one run as dense passes.  In the
+// lock-step walk above a ring pass costs the wave the same whether one lane or all 64 need it, and beyond the first
+// offset only some lanes do (all rings: a query far from every target point cannot rule rings out, its neighbours can;
+// hinted: 2.2 of a query's four rings survive their bounds, not the same ones for every lane).  Here the
 // wave walks the first PCP_POOL_LOCKSTEP offsets together as before; for the offsets behind them every lane only TESTS
 // its ring's bounds and puts the rings it cannot rule out on a list the wave shares (LDS; offset by offset and lane by
 // lane, so entries that lie together are neighbouring queries on the same or a neighbouring ring and their gathers
@@ -410,7 +411,8 @@ __device__ __forceinline__ int find_closest(const Target& T, const float4 q, flo
 // (distance bits, ring, index) by an LDS minimum, which is the shader's order: smallest distance, then lowest ring.
 // The owners read their word back after every pass, so later bounds are tested against the tightened minimum.
 // A ring that is searched although the lock-step walk would have ruled it out by then can neither hold nor tie the
-// minimum, so the result is the same triple (point, ring, distance).  Needs Zs <= 256 and n_a <= 2^24.
+// minimum, so the result is the same triple (point, ring, distance).  Needs Z <= 256 and n_a <= 2^24.  Every lane of
+// the wave must call (live = false for lanes without a query).
 #ifndef PCP_POOL_LOCKSTEP
 #define PCP_POOL_LOCKSTEP 1
 #endif
@@ -432,9 +434,13 @@ __device__ __forceinline__ int find_closest_pooled(const Target& T, const float4
     const float far = (v.x * v.x + v.z * v.z) * PCP_AZ_FAR;
     float mind = PCP_BIG;
     int glob = 0, ring = -1;
-    const int from = 0, to = T.Zs;
-    int centre = 0;
-    if (can_prune) {
+    int from = 0, to = T.Zs, centre = 0;          // the same ranges and starting ring as find_closest
+    if (hint != -1.0f) {
+        const int h = (int)hint;
+        from = max(0, h - 2);
+        to = min(T.Z, h + 2);
+        centre = min(max(h, from), to - 1);
+    } else if (can_prune) {
         float lo = PCP_BIG;
         for (int r = from; r < to; ++r) {
             const float lb = ring_lower_bound(T.stat[r], sq, cq, rho2);

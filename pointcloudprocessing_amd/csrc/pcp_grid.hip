@@ -219,15 +219,22 @@ __device__ __forceinline__ bool find_cell(const Cell* __restrict__ table, const 
 
 __global__ void k_gather_points(const double* __restrict__ xyz, const unsigned* __restrict__ vals, size_t n,
                                 const float4* __restrict__ normals_in, const unsigned* __restrict__ orig, long long first_id,
-                                GridPoint* __restrict__ pts, float4* __restrict__ normals) {
+                                const long long* __restrict__ ids, GridPoint* __restrict__ pts, float4* __restrict__ normals) {
     const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n) return;
     const unsigned i = vals[j];
     GridPoint p;
     p.x = xyz[3 * (size_t)i + 0]; p.y = xyz[3 * (size_t)i + 1]; p.z = xyz[3 * (size_t)i + 2];
-    p.id = first_id + (orig ? (long long)orig[i] : (long long)i);     // index in the caller's array (+ what came before it)
+    // index in the caller's array (+ what came before it); collected appends bring every point's id along
+    p.id = ids ? ids[i] : first_id + (orig ? (long long)orig[i] : (long long)i);
     pts[j] = p;
     if (normals_in) normals[j] = normals_in[i];
+}
+
+// ids of a batch that waits to be merged: first_id + (index in the caller's array)
+__global__ void k_pending_ids(const unsigned* __restrict__ orig, long long first_id, size_t n, long long* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = first_id + (orig ? (long long)orig[i] : (long long)i);
 }
 
 // Merge of two runs sorted by key into one: every element finds its place by one binary search in the
@@ -1029,6 +1036,13 @@ struct pcp_grid {
     int device = 0;
     hipStream_t own_stream = nullptr, stream = nullptr;
     float* comm_tile = nullptr;      // 64 floats: the partial tile of pcp_grid_icp_run_comm, made on first use
+    // scratch of the appends, kept between them (grow only): sort buffers and the sorted batch; a map fed frame by
+    // frame would otherwise allocate and free nine buffers per append
+    // appends collected between pcp_grid_collect_begin and pcp_grid_collect_end: coordinates and ids of the points waiting
+    bool collecting = false;
+    double* pend_xyz = nullptr; long long* pend_id = nullptr; size_t pend_n = 0, pend_cap = 0;
+    void* scr[9] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    size_t scr_bytes[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     // map
     size_t n = 0, cap = 0;
     double cell = 0.0;
@@ -1125,8 +1139,14 @@ int reserve_source(pcp_grid* g, size_t m) {
     return 0;
 }
 
+int check_collecting(const pcp_grid* g) {
+    if (g->collecting) return pcp_fail("appends are being collected: the map is not complete before pcp_grid_collect_end");
+    return 0;
+}
+
 int check_source(const pcp_grid* g) {
     if (!g) return pcp_fail("null grid");
+    if (check_collecting(g)) return 1;
     if (g->m == 0) return pcp_fail("no source cloud uploaded (pcp_grid_source)");
     return 0;
 }
@@ -1250,6 +1270,8 @@ int pcp_grid_destroy(pcp_grid* g) {
     void* p[] = {g->state, g->hb_trace, g->dx_trace, g->tile, g->sel_state, g->sel_hist, g->kd_partial, g->kd_out,
                  g->rt, g->mm, g->cell_count, g->comm_tile};
     for (void* q : p) if (q) PCP_CHECK(hipFree(q));
+    for (void* q : g->scr) if (q) PCP_CHECK(hipFree(q));
+    for (void* q : {(void*)g->pend_xyz, (void*)g->pend_id}) if (q) PCP_CHECK(hipFree(q));
     for (hipEvent_t e : {g->ev0, g->ev1, g->ev2, g->ev3}) if (e) PCP_CHECK(hipEventDestroy(e));
     PCP_CHECK(hipStreamDestroy(g->own_stream));
     delete g;
@@ -1296,26 +1318,48 @@ struct SortedRun {
     size_t n = 0;
     int lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
     int passes = 0;
+    bool owned = true;        // false: the buffers are the grid's append scratch and stay with it
     void release() {
-        for (void* q : {(void*)pts, (void*)keys, (void*)normals}) if (q) (void)hipFree(q);
+        if (owned)
+            for (void* q : {(void*)pts, (void*)keys, (void*)normals}) if (q) (void)hipFree(q);
         pts = nullptr; keys = nullptr; normals = nullptr; n = 0;
     }
 };
+
+// Slot `k` of the grid's append scratch with room for `bytes` (contents are not kept across a growth).
+static hipError_t grid_scratch(pcp_grid* g, int k, size_t bytes, void** out) {
+    if (g->scr_bytes[k] < bytes) {
+        if (g->scr[k]) (void)hipFree(g->scr[k]);
+        g->scr[k] = nullptr;
+        g->scr_bytes[k] = 0;
+        size_t want = bytes + bytes / 2;
+        if (want < 4096) want = 4096;
+        const hipError_t e = hipMalloc(&g->scr[k], want);
+        if (e != hipSuccess) return e;
+        g->scr_bytes[k] = want;
+    }
+    *out = g->scr[k];
+    return hipSuccess;
+}
 
 // Keys, stable radix sort by key, points gathered into that order.  d_ids (or null) maps the rows of
 // d_xyz to indices in the caller's array; ids are first_id + that index.  Events ev0..ev2 bracket the
 // whole and the sort when `timed`.
 static int sort_run(pcp_grid* g, const double* d_xyz, const float4* d_nrm, const unsigned* d_ids, long long first_id,
-                    size_t n, double cell, bool timed, SortedRun* out) {
+                    size_t n, double cell, bool timed, SortedRun* out, bool pooled = false, const long long* abs_ids = nullptr) {
     hipStream_t s = g->stream;
     unsigned long long *k0 = nullptr, *k1 = nullptr;
     unsigned *v0 = nullptr, *v1 = nullptr, *hist = nullptr, *totals = nullptr, *base = nullptr;
     const int nblk = (int)((n + RS_TILE - 1) / RS_TILE);
     SortedRun run;
+    run.owned = !pooled;
     auto cleanup = [&]() {
+        if (pooled) return;
         for (void* q : {(void*)k0, (void*)k1, (void*)v0, (void*)v1, (void*)hist, (void*)totals, (void*)base})
             if (q) (void)hipFree(q);
     };
+    int slot = 0;
+    auto get = [&](void** p, size_t bytes) { return pooled ? grid_scratch(g, slot++, bytes, p) : hipMalloc(p, bytes); };
 #define GRID_TRY(expr)                                                                                      \
     do {                                                                                                    \
         hipError_t e_ = (expr);                                                                             \
@@ -1339,13 +1383,13 @@ static int sort_run(pcp_grid* g, const double* d_xyz, const float4* d_nrm, const
     }
     for (int a = 0; a < 3; ++a) { run.lo[a] = mm[a]; run.hi[a] = mm[3 + a]; }
     // keys + sort
-    GRID_TRY(hipMalloc(&k0, n * 8));
-    GRID_TRY(hipMalloc(&k1, n * 8));
-    GRID_TRY(hipMalloc(&v0, n * 4));
-    GRID_TRY(hipMalloc(&v1, n * 4));
-    GRID_TRY(hipMalloc(&hist, (size_t)256 * nblk * 4));
-    GRID_TRY(hipMalloc(&totals, 256 * 4));
-    GRID_TRY(hipMalloc(&base, 256 * 4));
+    GRID_TRY(get((void**)&k0, n * 8));
+    GRID_TRY(get((void**)&k1, n * 8));
+    GRID_TRY(get((void**)&v0, n * 4));
+    GRID_TRY(get((void**)&v1, n * 4));
+    GRID_TRY(get((void**)&hist, (size_t)256 * nblk * 4));
+    GRID_TRY(get((void**)&totals, 256 * 4));
+    GRID_TRY(get((void**)&base, 256 * 4));
     hipLaunchKernelGGL(k_cell_keys, dim3(blocks_for(n, 256)), dim3(256), 0, s, d_xyz, n, cell, k0, v0);
     if (timed) GRID_TRY(hipEventRecord(g->ev1, s));
     unsigned long long* kin = nullptr;
@@ -1353,9 +1397,9 @@ static int sort_run(pcp_grid* g, const double* d_xyz, const float4* d_nrm, const
     run.passes = radix_sort_pairs_varying(s, k0, k1, v0, v1, n, varying_key_bits(run.lo, run.hi), hist, totals, base, &kin, &vin);
     if (timed) GRID_TRY(hipEventRecord(g->ev2, s));
     GRID_TRY(hipGetLastError());
-    GRID_TRY(hipMalloc(&run.pts, n * sizeof(GridPoint)));
-    if (d_nrm) GRID_TRY(hipMalloc(&run.normals, n * 16));
-    hipLaunchKernelGGL(k_gather_points, dim3(blocks_for(n, 256)), dim3(256), 0, s, d_xyz, vin, n, d_nrm, d_ids, first_id,
+    GRID_TRY(get((void**)&run.pts, n * sizeof(GridPoint)));
+    if (d_nrm) GRID_TRY(get((void**)&run.normals, n * 16));
+    hipLaunchKernelGGL(k_gather_points, dim3(blocks_for(n, 256)), dim3(256), 0, s, d_xyz, vin, n, d_nrm, d_ids, first_id, abs_ids,
                        run.pts, run.normals);
     GRID_TRY(hipGetLastError());
     // the sorted keys stay (in whichever of the two sort buffers they ended); everything else goes
@@ -1432,9 +1476,34 @@ static int build_device(pcp_grid* g, const double* d_xyz, const float4* d_nrm, c
 // Points already on the device join the resident map: sorted among themselves, merged into the second
 // set of buffers (which then becomes the first), table rebuilt from the merged keys.  The result is the
 // map a build of all points in order of their ids would give: same order, same cells.
-static int append_device(pcp_grid* g, const double* d_xyz, const float4* d_nrm, const unsigned* d_ids, long long first_id, size_t m) {
+static int append_device(pcp_grid* g, const double* d_xyz, const float4* d_nrm, const unsigned* d_ids, long long first_id, size_t m,
+                         const long long* abs_ids = nullptr) {
     hipStream_t s = g->stream;
     if (m == 0) return 0;
+    if (g->collecting && !abs_ids) {
+        // the batch waits: coordinates and ids go behind what is waiting already (this stream; the caller's buffer is free
+        // again once the stream has passed the copy, which the caller's next wait on the grid covers)
+        if (d_nrm) return pcp_fail("collected appends carry no normals");
+        if (g->pend_n + m > g->pend_cap) {
+            size_t cap = std::max<size_t>(g->pend_cap * 2, std::max<size_t>(g->pend_n + m, 1u << 20));
+            double* nx = nullptr; long long* ni = nullptr;
+            hipError_t e = hipMalloc(&nx, cap * 24);
+            if (e == hipSuccess) e = hipMalloc(&ni, cap * 8);
+            if (e == hipSuccess && g->pend_n) e = hipMemcpyAsync(nx, g->pend_xyz, g->pend_n * 24, hipMemcpyDeviceToDevice, s);
+            if (e == hipSuccess && g->pend_n) e = hipMemcpyAsync(ni, g->pend_id, g->pend_n * 8, hipMemcpyDeviceToDevice, s);
+            if (e == hipSuccess) e = hipStreamSynchronize(s);
+            if (e != hipSuccess) { if (nx) (void)hipFree(nx); if (ni) (void)hipFree(ni); return pcp_fail("room for %zu waiting points: %s", cap, hipGetErrorString(e)); }
+            if (g->pend_xyz) (void)hipFree(g->pend_xyz);
+            if (g->pend_id) (void)hipFree(g->pend_id);
+            g->pend_xyz = nx; g->pend_id = ni; g->pend_cap = cap;
+        }
+        PCP_CHECK(hipMemcpyAsync(g->pend_xyz + 3 * g->pend_n, d_xyz, m * 24, hipMemcpyDeviceToDevice, s));
+        hipLaunchKernelGGL(k_pending_ids, dim3(blocks_for(m, 256)), dim3(256), 0, s, d_ids, first_id, m, g->pend_id + g->pend_n);
+        PCP_CHECK(hipGetLastError());
+        PCP_CHECK(hipStreamSynchronize(s));        // the caller may reuse its buffer when the call returns
+        g->pend_n += m;
+        return 0;
+    }
     if (g->n + m >= (1ull << 31)) return pcp_fail("%zu map points exceed the 2^31 limit of one grid", g->n + m);
     if (g->n && g->have_normals && !d_nrm) {
         if (!g->normals_estimated) return pcp_fail("the map carries the caller's normals: appended points need them too");
@@ -1445,7 +1514,8 @@ static int append_device(pcp_grid* g, const double* d_xyz, const float4* d_nrm, 
     if (g->n && !g->have_normals && d_nrm) return pcp_fail("the map carries no normals");
     g->nn_valid = false;
     SortedRun run;
-    if (sort_run(g, d_xyz, d_nrm, d_ids, first_id, m, g->cell, false, &run)) return 1;
+    // a batch that joins a map is sorted in the grid's scratch; the first batch of an empty map becomes the map itself
+    if (sort_run(g, d_xyz, d_nrm, d_ids, first_id, m, g->cell, false, &run, g->n != 0, abs_ids)) return 1;
     g->sort_passes = run.passes;
     if (g->n == 0) {
         if (free_map(g)) { run.release(); return 1; }
@@ -1498,6 +1568,7 @@ static int check_build_args(pcp_grid* g, const double* xyz, size_t n, double cel
 
 int pcp_grid_build(pcp_grid* g, const double* xyz, size_t n, double cell, const float* normals_xyzw) {
     if (check_build_args(g, xyz, n, cell)) return 1;
+    if (check_collecting(g)) return 1;
     PCP_CHECK(hipSetDevice(g->device));
     hipStream_t s = g->stream;
     PCP_CHECK(hipStreamSynchronize(s));
@@ -1522,6 +1593,7 @@ int pcp_grid_build(pcp_grid* g, const double* xyz, size_t n, double cell, const 
 int pcp_grid_build_slab(pcp_grid* g, const double* xyz, size_t n, double cell, const float* normals_xyzw,
                         double own_cell, unsigned long long lo, unsigned long long hi, size_t* n_kept) {
     if (check_build_args(g, xyz, n, cell)) return 1;
+    if (check_collecting(g)) return 1;
     if (!(own_cell > 0.0)) return pcp_fail("partition cell size must be positive");
     if (lo > hi) return pcp_fail("owned key range is empty");
     PCP_CHECK(hipSetDevice(g->device));
@@ -1632,6 +1704,28 @@ static int append_host(pcp_grid* g, const double* xyz, size_t n, const float* no
     return rc;
 }
 
+int pcp_grid_collect_begin(pcp_grid* g) {
+    if (!g) return pcp_fail("null grid");
+    if (!(g->cell > 0.0)) return pcp_fail("the grid has no cell size yet: call pcp_grid_build first (an empty map will do)");
+    if (g->collecting) return pcp_fail("appends are being collected already");
+    g->collecting = true;
+    g->pend_n = 0;
+    return 0;
+}
+
+int pcp_grid_collect_end(pcp_grid* g) {
+    if (!g) return pcp_fail("null grid");
+    if (!g->collecting) return pcp_fail("no appends are being collected");
+    PCP_CHECK(hipSetDevice(g->device));
+    g->collecting = false;
+    const size_t m = g->pend_n;
+    g->pend_n = 0;
+    if (m == 0) return 0;
+    // one sort, one merge and one cell table for everything that waited: the map an append per batch would have left
+    // (a cell's points in the order of their ids) as long as the batches' ids ascend, as they do for appends in general
+    return append_device(g, g->pend_xyz, nullptr, nullptr, 0, m, g->pend_id);
+}
+
 int pcp_grid_append(pcp_grid* g, const double* xyz, size_t n, const float* normals_xyzw, long long first_id) {
     return append_host(g, xyz, n, normals_xyzw, first_id, false, 1.0, 0, 0, nullptr);
 }
@@ -1707,6 +1801,7 @@ int pcp_grid_partition(int device, const double* xyz, size_t n, double own_cell,
 int pcp_grid_info(pcp_grid* g, unsigned long long* n_points, unsigned long long* n_cells, int* extent3,
                   int* sort_passes, float* build_ms, float* sort_ms) {
     if (!g) return pcp_fail("null grid");
+    if (check_collecting(g)) return 1;
     if (n_points) *n_points = g->n;
     if (n_cells) *n_cells = g->n_cells;
     if (extent3) for (int a = 0; a < 3; ++a) extent3[a] = g->ext[a];
@@ -1718,6 +1813,7 @@ int pcp_grid_info(pcp_grid* g, unsigned long long* n_points, unsigned long long*
 
 int pcp_grid_sorted_ids(pcp_grid* g, long long* ids, double* xyz) {
     if (!g) return pcp_fail("null grid");
+    if (check_collecting(g)) return 1;
     PCP_CHECK(hipSetDevice(g->device));
     std::vector<GridPoint> h(g->n);
     if (g->n) PCP_CHECK(hipMemcpy(h.data(), g->pts, g->n * sizeof(GridPoint), hipMemcpyDeviceToHost));
@@ -1731,6 +1827,7 @@ int pcp_grid_sorted_ids(pcp_grid* g, long long* ids, double* xyz) {
 int pcp_grid_estimate_normals(pcp_grid* g, double radius, int min_points, const double* viewpoint3, float* normals_xyzw,
                               unsigned* counts) {
     if (!g) return pcp_fail("null grid");
+    if (check_collecting(g)) return 1;
     if (!(radius > 0.0) || !std::isfinite(radius)) return pcp_fail("radius must be positive and finite");
     if (g->n == 0) return pcp_fail("the grid holds no map (pcp_grid_build)");
     const double cells = std::ceil(radius / g->cell);

@@ -328,10 +328,10 @@ __device__ __forceinline__ void ls_body(const LsArgs& A, char* smem, const unsig
         float h = in ? hint[i] : -1.0f;
         bool pooled = false;
         if (POOL) {
-            // a wave of a freshly prepared pair: nobody has a hint, the all-rings search runs as dense passes
+            // the wave's ring searches behind the first one run as dense passes
             __shared__ unsigned long long pool_slot[64];
             __shared__ unsigned short pool_items[128];
-            if (__all(h == -1.0f) && T.Zs <= 256) {
+            if (T.Z <= 256) {
                 pooled = true;
                 nn = find_closest_pooled(T, q, in, h, pool_slot, pool_items);
                 if (!in) nn = 0;
@@ -816,8 +816,8 @@ int launch_first_rings(pcp_ctx* c) {
     return 0;
 }
 
-bool use_pool() {      // PCP_LS_POOL=0: the first dispatch of a batch walks all rings in lock step like the later ones
-    static const bool pool = [] { const char* e = getenv("PCP_LS_POOL"); return !(e && e[0] == '0'); }();
+int use_pool() {       // PCP_LS_POOL: 0 = every dispatch of a batch walks its rings in lock step, 1 = the first one pools, 2 = all do
+    static const int pool = [] { const char* e = getenv("PCP_LS_POOL"); return e ? atoi(e) : 1; }();
     return pool;
 }
 
@@ -1544,7 +1544,7 @@ int pcp_batch_icp_launch(pcp_batch* b, int mode, int max_iter, float tol, int fu
             }
             PCP_CHECK(hipEventRecord(b->prof_events[2 * it], b->stream));
         }
-        if (it == 0 && use_pool()) {
+        if ((it == 0 && use_pool() >= 1) || use_pool() >= 2) {
             if (mode == PCP_MODE_POINT) hipLaunchKernelGGL((k_ls_batch_first<PCP_MODE_POINT>), grid, block, sm, b->stream, b->ls_dev);
             else hipLaunchKernelGGL((k_ls_batch_first<PCP_MODE_PLANE>), grid, block, sm, b->stream, b->ls_dev);
         } else if (mode == PCP_MODE_POINT) hipLaunchKernelGGL((k_ls_batch<PCP_MODE_POINT>), grid, block, sm, b->stream, b->ls_dev);

@@ -513,7 +513,7 @@ int pcp_seq_submit_placed(pcp_seq* s, const float* const* raw_xyzi, const int* n
             }
             PCP_CHECK(hipEventRecord(s->prof_events[2 * it], q));
         }
-        if (it == 0 && use_pool()) {
+        if ((it == 0 && use_pool() >= 1) || use_pool() >= 2) {
             if (mode == PCP_MODE_POINT) hipLaunchKernelGGL((k_ls_batch_first<PCP_MODE_POINT>), grid, block, sm, q, s->ls_dev);
             else hipLaunchKernelGGL((k_ls_batch_first<PCP_MODE_PLANE>), grid, block, sm, q, s->ls_dev);
         } else if (mode == PCP_MODE_POINT) hipLaunchKernelGGL((k_ls_batch<PCP_MODE_POINT>), grid, block, sm, q, s->ls_dev);

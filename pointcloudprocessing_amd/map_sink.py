@@ -38,6 +38,15 @@ class MapSink:
         self.voxels_fed += rows
         return n
 
+    def collecting(self):
+        """Context manager for a producer that hands over many batches in a row (Voxelizer.stageAllRemaningVoxels): the
+        map takes them all in at the end, in one merge (CellGrid.collect)."""
+        grid = self.target if hasattr(self.target, "collect") else getattr(getattr(self.target, "backend", None), "grid", None)
+        if self.compute is None or grid is None or not hasattr(grid, "collect"):
+            import contextlib
+            return contextlib.nullcontext()
+        return grid.collect()
+
     def frameVoxelized(self, voxel_points, colors, separate_colors):
         """VoxelManager.frameVoxelized's signature; the colours are the renderer's business, not the map's."""
         if len(voxel_points):

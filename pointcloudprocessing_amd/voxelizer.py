@@ -279,6 +279,16 @@ class Voxelizer:
             raise RuntimeError("the device's voxel map has been replaced (another Voxelizer took this ComputeShader): "
                                "this map can no longer be staged from its resident statistics")
         stats = self._voxel_stats if resident else self.voxel_stats
+        # a sink that resolves the staged rows on the device never looks at them on the host: they are not fetched
+        # (4 KB per row), only counted
+        on_device = (resident and getattr(self.voxman, "compute", None) is not None and hasattr(self.voxman, "framesStagedOnDevice")
+                     and not (self.renderer is None and getattr(self.voxman, "needs_renderer", True)))
+        if on_device:
+            out, count = self.compute.prepareDispatchVoxelStager(
+                self._voxel_index, self.stored_voxels, self.max_points, stats, filter_outliers=self.filter_outliers,
+                stage_everything=everything, fetch_rows=False)
+            self._stats_stale = True
+            return _StagedRows(self.compute, count, self.max_points)
         out, rows = self.compute.prepareDispatchVoxelStager(
             self._voxel_index, self.stored_voxels, self.max_points, stats,
             filter_outliers=self.filter_outliers, stage_everything=everything)
@@ -320,12 +330,16 @@ class Voxelizer:
             rows = self._stage(True)
             self._hand_off(rows)
             return rows
-        while True:
-            rows = one_pass()
-            if not np.any(rows):
-                for _ in range(10):
-                    one_pass()
-                break
+        import contextlib
+        # a sink that can take many batches in one go (map_sink.MapSink on the device) merges them when the passes are over
+        gather = self.voxman.collecting() if hasattr(self.voxman, "collecting") else contextlib.nullcontext()
+        with gather:
+            while True:
+                rows = one_pass()
+                if not (len(rows) if isinstance(rows, _StagedRows) else np.any(rows)):
+                    for _ in range(10):
+                        one_pass()
+                    break
 
     # ------------------------------------------------------------------ host half of the map
     def vectorizedGetVoxelCoord(self, np_points):

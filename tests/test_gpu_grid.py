@@ -349,6 +349,36 @@ def test_appending_frames_equals_building_the_whole(frames):
         g_all.cleanup()
 
 
+def test_collected_appends_equal_appends_one_by_one(frames):
+    """pcp_grid_collect_begin / _end: batches handed over inside are merged into the map together at the end -- the same
+    map (ids, order, cells, answers) as an append per batch; nothing may read the map in between."""
+    from pointcloudprocessing_amd._lib import PcpError
+    a, b = frames
+    batches = [b[:40000] + np.array([0.3, 0.0, 0.1]), b[40000:40007], a[::3] * np.array([1.0, 1.0, -1.0]),
+               b[:5000] + np.array([-700.0, 35.0, 900.0])]
+    g_one, g_col = CellGrid(a, cell=0.5), CellGrid(a, cell=0.5)
+    try:
+        for extra in batches:
+            g_one.append(extra)
+        with g_col.collect():
+            for extra in batches:
+                g_col.append(extra)
+            with pytest.raises(PcpError, match="being collected"):
+                g_col.query(b[:10])
+            with pytest.raises(PcpError, match="being collected"):
+                g_col.info()
+        _same_grid(g_one, g_col, np.concatenate([b[::11], batches[3][::7] + 0.05]))
+        with g_col.collect():                      # nothing handed over: the map stays as it is
+            pass
+        _same_grid(g_one, g_col, b[::29])
+        with pytest.raises(PcpError, match="normals"):
+            with g_col.collect():
+                g_col.append(b[:100], normals=np.ones((100, 3), np.float32))
+    finally:
+        g_one.cleanup()
+        g_col.cleanup()
+
+
 def test_appending_with_normals_and_the_rules_around_them(frames):
     a, b = frames[0][::5], frames[1][::5]
     rng = np.random.default_rng(2)
