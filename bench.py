@@ -444,6 +444,12 @@ def extras(raws, device):
             grid = CellGrid(cloud, cell=size, device=device)
         else:
             grid.rebuild(cloud, cell=size)
+        # the same search with the cell edge refined until an occupied cell holds at most 16 points (same answers)
+        grid.rebuild(cloud, cell=size, refine=16)
+        fine_cell = grid.cell
+        grid.query(q)
+        fine_ms = min(grid.query(return_kernel_ms=True)[2] for _ in range(3))
+        grid.rebuild(cloud, cell=size)
         info = grid.info()
         grid.query(q)
         qms = min(grid.query(return_kernel_ms=True)[2] for _ in range(3))
@@ -458,6 +464,8 @@ def extras(raws, device):
                      "cells": int(info["cells"]), "morton_sort_ms": float(info["sort_ms"]), "sort_passes": int(info["sort_passes"]),
                      "sort_gb_per_s": 24.0 * len(cloud) * info["sort_passes"] / sort_s / 1e9 if sort_s else None,
                      "grid_build_ms": float(info["build_ms"]), "nn_ms": float(qms), "nn_queries_per_s": len(q) / (qms * 1e-3),
+                     "nn_refined": {"cell_m": fine_cell, "nn_ms": float(fine_ms), "nn_queries_per_s": len(q) / (fine_ms * 1e-3),
+                                    "what": "CellGrid(refine=16): the search cell halved until an occupied cell holds <= 16 points"},
                      "roofline": {
                          "voxelize": roof(28.0 * len(cloud) + 16.0 * stored, fed[0], "the frame feed (k_feed_voxelize, k_voxel_stage, radix "
                                           "sort of the unknown points, k_feed_new_voxels, k_feed_shift_old: 26 launches per sweep)",

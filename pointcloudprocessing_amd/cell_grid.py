@@ -31,17 +31,28 @@ def auto_cell(points):
 
 
 class CellGrid:
-    def __init__(self, np_points, cell=None, normals=None, device=0, slab=None):
+    def __init__(self, np_points, cell=None, normals=None, device=0, slab=None, refine=None):
         self._lib = _lib.load()
         self._g = C.c_void_p()
         check(self._lib.pcp_grid_create(int(device), C.byref(self._g)))
         self.device = int(device)
-        self.rebuild(np_points, cell, normals, slab)
+        self.rebuild(np_points, cell, normals, slab, refine)
 
-    def rebuild(self, np_points, cell=None, normals=None, slab=None):
+    def rebuild(self, np_points, cell=None, normals=None, slab=None, refine=None):
         """slab = (own_cell, lo, hi): keep only the points whose partition cell (edge own_cell) or one of
         its 26 neighbours has its key in [lo, hi) -- the share of a map split over ranks, selected on the
-        device; query results keep indexing np_points."""
+        device; query results keep indexing np_points.
+        refine = N: the answers of an exact search do not depend on the cell size, its speed does (a query scans its
+        cell and the shells around it point by point): while an occupied cell holds more than N points on average the
+        cell edge is halved and the grid built again (at most four times; a build is a few sorts)."""
+        if refine:
+            self.rebuild(np_points, cell, normals, slab)
+            for _ in range(4):
+                info = self.info()
+                if info["cells"] == 0 or info["points"] <= refine * info["cells"]:
+                    break
+                self.rebuild(np_points, self.cell / 2.0, normals, slab)
+            return
         pts = np.ascontiguousarray(np.asarray(np_points, dtype=np.float64)[:, :3])
         self.data = pts                                   # scipy's KDTree.data
         self.n = len(pts)

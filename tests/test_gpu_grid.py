@@ -100,6 +100,21 @@ def test_query_is_independent_of_the_cell_size(frames, cell):
     assert_same_neighbours(a, b, idx, dist, ref_i, ref_d)
 
 
+def test_refined_grid_gives_the_same_neighbours(frames):
+    """CellGrid(refine=N) halves the cell edge until an occupied cell holds at most N points: faster, same answers."""
+    a, b = frames[0], frames[1][::11]
+    coarse, fine = CellGrid(a, cell=4.0), CellGrid(a, cell=4.0, refine=16)
+    try:
+        assert fine.cell in (2.0, 1.0, 0.5, 0.25) and fine.info()["points"] <= 16 * fine.info()["cells"]
+        assert coarse.info()["points"] > 16 * coarse.info()["cells"]
+        d0, i0 = coarse.query(b)
+        d1, i1 = fine.query(b)
+        assert np.array_equal(i0, i1) and np.array_equal(d0, d1)
+    finally:
+        coarse.cleanup()
+        fine.cleanup()
+
+
 def test_ties_go_to_the_lowest_index_and_distances_are_bitwise():
     rng = np.random.default_rng(5)
     a = rng.integers(-6, 7, (3000, 3)).astype(np.float64) * 0.25       # many duplicates and ties
