@@ -586,6 +586,9 @@ int pcp_seq_collect_poses(pcp_seq* seq, int ticket, double* t_opt, double* R_opt
  * they processed. */
 int pcp_seq_profile_enable(pcp_seq* seq, int on);
 int pcp_seq_profile_read(pcp_seq* seq, float* ls_ms, int* launches, long long* points);
+/* The same launches one by one, in the order of the iterations: ms_each[i] (i < capacity) receives the duration of the
+ * launch of iteration i, launches their number.  Iteration 0 searches all rings (hint -1) and runs its own kernel. */
+int pcp_seq_profile_read_launches(pcp_seq* seq, float* ms_each, int capacity, int* launches);
 /* ---------------------------------------------------------------------------
  * The per-frame driver loop of a drive as one stream of device work.
  * EnvironmentConstructor.calculateTransition_imu (EnvironmentConstructor.py:154-265) handles a frame on the host: guess =

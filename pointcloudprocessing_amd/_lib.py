@@ -158,6 +158,7 @@ SIGNATURES = {
     "pcp_seq_collect_poses": (C.c_int, [C.c_void_p, C.c_int, _f64p, _f64p, _f32p, C.c_int, _i32p, _i32p, _i32p]),
     "pcp_seq_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "pcp_seq_profile_read": (C.c_int, [C.c_void_p, _f32p, _i32p, C.POINTER(C.c_longlong)]),
+    "pcp_seq_profile_read_launches": (C.c_int, [C.c_void_p, _f32p, C.c_int, _i32p]),
     "pcp_chain_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "pcp_chain_destroy": (C.c_int, [C.c_void_p]),
     "pcp_chain_reset": (C.c_int, [C.c_void_p]),

@@ -613,6 +613,19 @@ int pcp_seq_profile_read(pcp_seq* s, float* ls_ms, int* launches, long long* poi
     return 0;
 }
 
+int pcp_seq_profile_read_launches(pcp_seq* s, float* ms_each, int capacity, int* launches) {
+    if (!s) return pcp_fail("null sequence");
+    if (!ms_each || !launches || capacity < 0) return pcp_fail("null output");
+    if (s->in_flight[0] || s->in_flight[1]) return pcp_fail("collect the submissions in flight first");
+    PCP_CHECK(hipSetDevice(s->device));
+    PCP_CHECK(hipStreamSynchronize(s->compute));
+    const int n = s->last_longest < s->prof_launches ? s->last_longest : s->prof_launches;
+    for (int i = 0; i < n && i < capacity; ++i)
+        PCP_CHECK(hipEventElapsedTime(&ms_each[i], s->prof_events[2 * i], s->prof_events[2 * i + 1]));
+    *launches = n;
+    return 0;
+}
+
 int pcp_host_alloc(size_t bytes, void** out) {
     if (!out) return pcp_fail("null out pointer");
     *out = nullptr;

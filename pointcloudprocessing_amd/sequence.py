@@ -136,6 +136,12 @@ class SequencePipeline:
         check(self._lib.pcp_seq_profile_read(self._seq, C.byref(ms), C.byref(n), C.byref(pts)))
         return ms.value, n.value, pts.value
 
+    def profile_read_launches(self):
+        """The same launches one by one: list of ms, entry i the launch of iteration i (entry 0 searches all rings)."""
+        ms, n = (C.c_float * 64)(), C.c_int(0)
+        check(self._lib.pcp_seq_profile_read_launches(self._seq, ms, 64, C.byref(n)))
+        return [ms[i] for i in range(min(n.value, 64))]
+
     def close(self):
         if self._seq:
             self._lib.pcp_seq_destroy(self._seq)
