@@ -1036,6 +1036,7 @@ struct pcp_grid {
     int device = 0;
     hipStream_t own_stream = nullptr, stream = nullptr;
     float* comm_tile = nullptr;      // 64 floats: the partial tile of pcp_grid_icp_run_comm, made on first use
+    long long id_end = 0;            // one past the highest id any build or append has brought: appends must not go below it
     // scratch of the appends, kept between them (grow only): sort buffers and the sorted batch; a map fed frame by
     // frame would otherwise allocate and free nine buffers per append
     // appends collected between pcp_grid_collect_begin and pcp_grid_collect_end: coordinates and ids of the points waiting
@@ -1555,7 +1556,14 @@ static int append_device(pcp_grid* g, const double* d_xyz, const float4* d_nrm, 
     int lo[3], hi[3];
     for (int a = 0; a < 3; ++a) { lo[a] = std::min(g->lo[a], run.lo[a]); hi[a] = std::max(g->hi[a], run.hi[a]); }
     set_bounds(g, lo, hi);
-    return install_table(g);
+    if (install_table(g)) {
+        // merged entries without a cell table cannot be searched: the map is given up rather than left half made
+        g->n = 0;
+        g->n_cells = 0;
+        g->nn_valid = false;
+        return 1;
+    }
+    return 0;
 }
 
 static int check_build_args(pcp_grid* g, const double* xyz, size_t n, double cell) {
@@ -1585,6 +1593,7 @@ int pcp_grid_build(pcp_grid* g, const double* xyz, size_t n, double cell, const 
         if (e != hipSuccess) rc = pcp_fail("uploading the map failed: %s", hipGetErrorString(e));
     }
     if (!rc) rc = build_device(g, d_xyz, d_nrm, nullptr, n, cell);
+    if (!rc) g->id_end = (long long)n;
     if (d_xyz) (void)hipFree(d_xyz);
     if (d_nrm) (void)hipFree(d_nrm);
     return rc;
@@ -1609,7 +1618,7 @@ int pcp_grid_build_slab(pcp_grid* g, const double* xyz, size_t n, double cell, c
         for (void* q : {(void*)d_xyz, (void*)d_keep, (void*)d_nrm, (void*)d_nkeep, (void*)d_ids, (void*)d_counts, (void*)d_bad})
             if (q) (void)hipFree(q);
     };
-    if (n == 0) return build_device(g, nullptr, nullptr, nullptr, 0, cell);
+    if (n == 0) { g->id_end = 0; return build_device(g, nullptr, nullptr, nullptr, 0, cell); }
     hipError_t e = hipMalloc(&d_xyz, n * 24);
     if (e == hipSuccess) e = hipMemcpyAsync(d_xyz, xyz, n * 24, hipMemcpyHostToDevice, s);
     if (e == hipSuccess) e = hipMalloc(&d_keep, n * 24);
@@ -1634,6 +1643,7 @@ int pcp_grid_build_slab(pcp_grid* g, const double* xyz, size_t n, double cell, c
     if (e != hipSuccess) rc = pcp_fail("selecting the slab failed: %s", hipGetErrorString(e));
     else if (bad) rc = pcp_fail("map coordinates must be finite and within 2^20 partition cells of the origin");
     if (!rc) rc = build_device(g, d_keep, d_nkeep, d_ids, (size_t)kept, cell);
+    if (!rc) g->id_end = (long long)n;          // ids are places in the caller's whole array
     cleanup();
     if (!rc && n_kept) *n_kept = kept;
     return rc;
@@ -1647,6 +1657,10 @@ static int append_host(pcp_grid* g, const double* xyz, size_t n, const float* no
     if (n && !xyz) return pcp_fail("xyz is null");
     if (n >= (1ull << 31)) return pcp_fail("%zu points exceed the 2^31 limit of one grid", n);
     if (first_id < 0) return pcp_fail("first_id must not be negative");
+    // equal keys keep resident entries in front of new ones: only with ids that go up from batch to batch is that the
+    // order a build of everything gives
+    if (first_id < g->id_end)
+        return pcp_fail("first_id %lld lies below the ids the map already holds (next free id: %lld)", first_id, g->id_end);
     if (n_kept) *n_kept = 0;
     if (n == 0) return 0;
     PCP_CHECK(hipSetDevice(g->device));
@@ -1699,6 +1713,7 @@ static int append_host(pcp_grid* g, const double* xyz, size_t n, const float* no
     }
     if (e != hipSuccess) rc = pcp_fail("uploading the points failed: %s", hipGetErrorString(e));
     if (!rc) rc = append_device(g, use_xyz, use_nrm, use_ids, first_id, kept);
+    if (!rc) g->id_end = first_id + (long long)n;
     cleanup();
     if (!rc && n_kept) *n_kept = kept;
     return rc;

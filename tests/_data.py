@@ -52,3 +52,11 @@ def kitti_all_raw():
     more = golden("kitti_seq2.npz")
     assert int(more["first_frame"]) == 12
     return kitti_sequence_raw() + lidar.unpack_raw_frames(more)
+
+
+def free_port():
+    """A rendezvous port nobody holds right now (bound to port 0 once and released)."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]

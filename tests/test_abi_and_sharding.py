@@ -13,6 +13,7 @@ import pytest
 
 import pointcloudprocessing_amd as pcp
 from pointcloudprocessing_amd import _lib, sharding
+from tests._data import free_port
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -128,7 +129,7 @@ dist.destroy_process_group()
 def test_two_rank_gloo_gather(tmp_path):
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29611", WORLD_SIZE="2", OMP_NUM_THREADS="2")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()), WORLD_SIZE="2", OMP_NUM_THREADS="2")
     procs = [subprocess.Popen([sys.executable, str(script), ROOT, str(tmp_path)], env=dict(env, RANK=str(r)))
              for r in range(2)]
     try:

@@ -7,7 +7,7 @@ from oracle import np_grid as NG
 from oracle import np_oracle as O
 from pointcloudprocessing_amd import PointcloudIcpContainer, lidar
 from pointcloudprocessing_amd.cell_grid import CellGrid, cell_keys
-from tests._data import bits, golden, kitti_pair
+from tests._data import bits, free_port, golden, kitti_pair
 
 pytestmark = pytest.mark.gpu
 
@@ -417,6 +417,9 @@ def test_appending_with_normals_and_the_rules_around_them(frames):
         g_inc.set_source(src)
         with pytest.raises(RuntimeError, match="normals"):
             g_inc.ls(1, 0.4)
+        # ids go up from batch to batch (equal cells keep resident points in front of new ones)
+        with pytest.raises(RuntimeError, match="below the ids"):
+            g_inc.append(b, first_id=3)
     finally:
         g_inc.cleanup()
         g_all.cleanup()
@@ -635,7 +638,7 @@ def test_two_ranks_sharing_the_gpu_register_like_one(tmp_path):
     single = S.MapRegistration(pts, 0.5, normals=nrm)
     script = tmp_path / "worker.py"
     script.write_text(MAP_WORKER)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29617", WORLD_SIZE="2")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()), WORLD_SIZE="2")
     procs = [subprocess.Popen([sys.executable, str(script), root, str(tmp_path)], env=dict(env, RANK=str(r)))
              for r in range(2)]
     try:

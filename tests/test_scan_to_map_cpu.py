@@ -8,6 +8,7 @@ import numpy as np
 
 from oracle import np_grid as NG
 from oracle.np_map_backend import OracleMapBackend
+from tests._data import free_port
 from pointcloudprocessing_amd import lidar, scan_to_map as S
 from pointcloudprocessing_amd.cell_grid import cell_keys
 
@@ -82,7 +83,7 @@ def test_two_rank_gloo_registration_equals_single_rank(tmp_path):
     t1, R1, dx1, _ = single.register(src, S.MODE_POINT, 0.4, max_iter=6)
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29613", WORLD_SIZE="2", OMP_NUM_THREADS="2")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()), WORLD_SIZE="2", OMP_NUM_THREADS="2")
     procs = [subprocess.Popen([sys.executable, str(script), ROOT, str(tmp_path)], env=dict(env, RANK=str(r)))
              for r in range(2)]
     try:

@@ -28,5 +28,12 @@ def test_static_scratch_sum_equals_workspace_sum_on_two_calls_in_a_row(compute):
         w, g = want.cpu().numpy(), got.cpu().numpy()
         assert np.array_equal(w.view(np.uint32), g.view(np.uint32))
         assert np.allclose(g.reshape(8, 8)[:6, :7], tiles_h.reshape(n, 8, 8)[:, :6, :7].astype(np.float64).sum(0), atol=2e-2)
+    # the property the entry point exists for: the device's free memory is the same before and after calls of it
+    # (hipMemGetInfo; the library and the runtime are warm from the calls above, torch allocates nothing in between)
+    free_before = torch.cuda.mem_get_info()[0]
+    for _ in range(3):                                         # `tiles` holds the last case's single tile
+        check(lib.pcp_hb_sum_static(ctx, C.c_void_p(tiles.data_ptr()), 1, C.c_void_p(got.data_ptr())))
+        check(lib.pcp_synchronize(ctx))
+    assert torch.cuda.mem_get_info()[0] == free_before
     with pytest.raises(PcpError, match="exceed"):
         check(lib.pcp_hb_sum_static(ctx, C.c_void_p(tiles.data_ptr()), 262145, C.c_void_p(got.data_ptr())))
