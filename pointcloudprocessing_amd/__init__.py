@@ -15,4 +15,5 @@ from .oxts import OXTS, OxtsDataReader  # noqa: F401
 from .voxelizer import Voxelizer  # noqa: F401
 from .sequence import PinnedFrames, SequencePipeline  # noqa: F401
 from .map_sink import MapSink  # noqa: F401
-from .chain import OdometryChain, chain_odometry  # noqa: F401
+from .chain import OdometryChain, chain_odometry, chain_odometry_files  # noqa: F401
+from .frame_files import FrameFileRuns, velodyne_files  # noqa: F401

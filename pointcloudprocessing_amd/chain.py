@@ -117,35 +117,57 @@ class OdometryChain:
             pass
 
 
-def chain_odometry(raw_frames, records, voxelizer=None, point_to_plane=True, iterations=10, run=32, device=0, max_points=131072,
-                   reset_every=10):
-    """A whole drive: [(imu_position, refined_position, imu_rotation, refined_rotation, time)] per frame -- the tuples
-    EnvironmentConstructor keeps in prev_poses (:181, :257) -- from raw frames and their OXTS records, in runs of `run`
-    frames with two runs in flight."""
-    from .sequence import PinnedFrames
+def _drive(runs, n_frames, records, voxelizer, point_to_plane, iterations, run, device, max_points, reset_every):
     rows, rots, steps, times = imu_rows(records)
-    pinned = PinnedFrames(raw_frames)
-    chain = OdometryChain(max_frames=min(run, len(raw_frames)), max_points=max_points, device=device, reset_every=reset_every)
+    chain = OdometryChain(max_frames=min(run, n_frames), max_points=max_points, device=device, reset_every=reset_every)
     out, imu_pos = [], np.zeros(3)
     try:
         pending = []
 
-        def take(lo, ticket):
+        def take(lo, ticket, slot):
             nonlocal imu_pos
             for j, (_, pos, _, R_opt, _, _) in enumerate(chain.collect(ticket)):
                 k = lo + j
                 imu_pos = imu_pos + steps[k] if k else np.zeros(3)
                 out.append((imu_pos, pos, rots[k], R_opt @ rots[k], times[k]))
+            runs.release(slot)
 
-        for lo in range(0, len(raw_frames), run):
-            hi = min(len(raw_frames), lo + run)
-            pending.append((lo, chain.submit([pinned[k] for k in range(lo, hi)], rows[lo:hi], point_to_plane=point_to_plane,
-                                             iterations=iterations, voxelizer=voxelizer)))
+        for lo, arrays, slot in runs:
+            pending.append((lo, chain.submit(arrays, rows[lo:lo + len(arrays)], point_to_plane=point_to_plane,
+                                             iterations=iterations, voxelizer=voxelizer), slot))
             if len(pending) == 2:
                 take(*pending.pop(0))
         for item in pending:
             take(*item)
     finally:
         chain.close()
-        pinned.close()
     return out
+
+
+def chain_odometry(raw_frames, records, voxelizer=None, point_to_plane=True, iterations=10, run=32, device=0, max_points=131072,
+                   reset_every=10):
+    """A whole drive: [(imu_position, refined_position, imu_rotation, refined_rotation, time)] per frame -- the tuples
+    EnvironmentConstructor keeps in prev_poses (:181, :257) -- from raw frames and their OXTS records, in runs of `run`
+    frames with two runs in flight."""
+    from .frame_files import MemoryRuns
+    from .sequence import PinnedFrames
+    pinned = PinnedFrames(raw_frames)
+    try:
+        return _drive(MemoryRuns(pinned, min(run, len(raw_frames))), len(raw_frames), records, voxelizer, point_to_plane,
+                      iterations, run, device, max_points, reset_every)
+    finally:
+        pinned.close()
+
+
+def chain_odometry_files(paths, records, voxelizer=None, point_to_plane=True, iterations=10, run=32, device=0, max_points=131072,
+                         reset_every=10):
+    """chain_odometry for frames that are still files (velodyne .bin in the order given; frame_files.velodyne_files sorts a
+    directory by name): a background thread reads the next run straight into page-locked memory while the current one is
+    on the device (the reference reads each file when its frame is due, LidarDataReader.py:144-150)."""
+    from .frame_files import FrameFileRuns
+    paths = list(paths)
+    runs = FrameFileRuns(paths, min(run, len(paths)), max_points=max_points)
+    try:
+        return _drive(runs, len(paths), records, voxelizer, point_to_plane, iterations, run, device, max_points, reset_every)
+    finally:
+        runs.close()

@@ -155,6 +155,32 @@ class SequencePipeline:
             pass
 
 
+def _pairs_of_runs(runs, n_frames, lo, local, point_to_plane, iterations, device, max_points, placements=None):
+    """Runs of frames (frame_files.MemoryRuns / FrameFileRuns: consecutive runs share one frame) through a
+    SequencePipeline, two submissions in flight; local[lo + first pair of a run + j] = (t_opt, R_opt)."""
+    pipe = SequencePipeline(min(runs.run, max(2, n_frames)), max_points=max_points, device=device)
+    try:
+        pending = []
+
+        def take(c0, ticket, slot):
+            for j, pose in enumerate(pipe.collect_with_poses(ticket)[2]):
+                local[lo + c0 + j] = pose
+            runs.release(slot)
+
+        for c0, arrays, slot in runs:
+            if len(arrays) < 2:
+                runs.release(slot)
+                continue
+            place = None if placements is None else placements[lo + c0:lo + c0 + len(arrays)]
+            pending.append((c0, pipe.submit(arrays, point_to_plane=point_to_plane, iterations=iterations, placements=place), slot))
+            if len(pending) == 2:
+                take(*pending.pop(0))
+        for item in pending:
+            take(*item)
+    finally:
+        pipe.close()
+
+
 def sequence_odometry_raw(raw_frames, point_to_plane=True, iterations=10, rank=0, world=1, device=0, chunk=64,
                           gather_device="cpu", max_points=131072):
     """Poses of every frame in the frame of the first, [(R_w, t_w)] with p0 = R_w p + t_w, from raw velodyne
@@ -162,29 +188,40 @@ def sequence_odometry_raw(raw_frames, point_to_plane=True, iterations=10, rank=0
     block once), each block runs through a SequencePipeline in chunks of `chunk` pairs; poses are gathered
     once (sharding.gather_poses) and chained on the host."""
     from . import sharding
+    from .frame_files import MemoryRuns
     n_pairs = len(raw_frames) - 1
     per = -(-n_pairs // world)
     lo, hi = min(n_pairs, rank * per), min(n_pairs, (rank + 1) * per)
     local = {}
     if hi > lo:
         pinned = PinnedFrames(raw_frames[lo:hi + 1])
-        pipe = SequencePipeline(min(chunk, hi - lo) + 1, max_points=max_points, device=device)
         try:
-            pending = []
-            for c0 in range(0, hi - lo, chunk):
-                c1 = min(hi - lo, c0 + chunk)
-                pending.append((c0, pipe.submit([pinned[k] for k in range(c0, c1 + 1)], point_to_plane=point_to_plane,
-                                                iterations=iterations)))
-                if len(pending) == 2:
-                    b0, t = pending.pop(0)
-                    for j, pose in enumerate(pipe.collect_with_poses(t)[2]):
-                        local[lo + b0 + j] = pose
-            for b0, t in pending:
-                for j, pose in enumerate(pipe.collect_with_poses(t)[2]):
-                    local[lo + b0 + j] = pose
+            _pairs_of_runs(MemoryRuns(pinned, min(chunk, hi - lo) + 1, min(chunk, hi - lo)), hi - lo + 1, lo, local,
+                           point_to_plane, iterations, device, max_points)
         finally:
-            pipe.close()
             pinned.close()
+    poses = sharding.gather_poses(local, n_pairs, rank, world, device=gather_device)
+    return sharding.compose_odometry(poses)
+
+
+def sequence_odometry_files(paths, point_to_plane=True, iterations=10, rank=0, world=1, device=0, chunk=64,
+                            gather_device="cpu", max_points=131072):
+    """sequence_odometry_raw for frames that are still files (velodyne .bin, in the order given: frame_files.velodyne_files
+    sorts a directory by name): a rank's files are read by a background thread straight into page-locked memory, one run
+    ahead of the registration (LidarDataReader.getNextFrame reads a file when its frame is due, LidarDataReader.py:144-150)."""
+    from . import sharding
+    from .frame_files import FrameFileRuns
+    paths = list(paths)
+    n_pairs = len(paths) - 1
+    per = -(-n_pairs // world)
+    lo, hi = min(n_pairs, rank * per), min(n_pairs, (rank + 1) * per)
+    local = {}
+    if hi > lo:
+        runs = FrameFileRuns(paths[lo:hi + 1], min(chunk, hi - lo) + 1, min(chunk, hi - lo), max_points=max_points)
+        try:
+            _pairs_of_runs(runs, hi - lo + 1, lo, local, point_to_plane, iterations, device, max_points)
+        finally:
+            runs.close()
     poses = sharding.gather_poses(local, n_pairs, rank, world, device=gather_device)
     return sharding.compose_odometry(poses)
 
@@ -223,25 +260,12 @@ def sequence_odometry_imu(raw_frames, records, point_to_plane=True, iterations=1
     lo, hi = min(n_pairs, rank * per), min(n_pairs, (rank + 1) * per)
     local = {}
     if hi > lo:
+        from .frame_files import MemoryRuns
         pinned = PinnedFrames(raw_frames[lo:hi + 1])
-        pipe = SequencePipeline(min(chunk, hi - lo) + 1, max_points=max_points, device=device)
         try:
-            pending = []
-
-            def take(b0, ticket):
-                for j, pose in enumerate(pipe.collect_with_poses(ticket)[2]):
-                    local[lo + b0 + j] = pose
-
-            for c0 in range(0, hi - lo, chunk):
-                c1 = min(hi - lo, c0 + chunk)
-                pending.append((c0, pipe.submit([pinned[k] for k in range(c0, c1 + 1)], point_to_plane=point_to_plane,
-                                                iterations=iterations, placements=place[lo + c0:lo + c1 + 1])))
-                if len(pending) == 2:
-                    take(*pending.pop(0))
-            for item in pending:
-                take(*item)
+            _pairs_of_runs(MemoryRuns(pinned, min(chunk, hi - lo) + 1, min(chunk, hi - lo)), hi - lo + 1, lo, local,
+                           point_to_plane, iterations, device, max_points, placements=place)
         finally:
-            pipe.close()
             pinned.close()
     pairs = sharding.gather_poses(local, n_pairs, rank, world, device=gather_device)
     imu_pos = refined = np.zeros(3)
