@@ -892,7 +892,7 @@ def main():
     if dist is not None and not args.no_extras:
         torch.cuda.synchronize()
         leg = run_leg_in_children(rank, dist, os.environ.get("PCP_BENCH_LEG_EXCHANGE", "rccl" if backend == "nccl" else "gloo"),
-                                  int(os.environ.get("PCP_BENCH_LEG_SECONDS", "240")))
+                                  int(os.environ.get("PCP_BENCH_LEG_SECONDS", "150")))
         if out is not None:
             out["scan_to_map"] = leg
     if out is not None:
