@@ -104,7 +104,7 @@ static __global__ void __launch_bounds__(256) k_rs_base(const unsigned* __restri
 // keys of one digit leave as one run of consecutive addresses instead of one 8-byte write per key.
 static __device__ __forceinline__ void
 rs_scatter_body(const unsigned long long* __restrict__ keys_in, const unsigned* __restrict__ vals_in, size_t n, int shift,
-                const unsigned* __restrict__ hist, const unsigned* __restrict__ base, int nblk,
+                const unsigned goff,           // thread d: first place in the output of this tile's keys of digit d
                 unsigned long long* __restrict__ keys_out, unsigned* __restrict__ vals_out) {
     __shared__ unsigned cnt[4][256];
     __shared__ unsigned tstart[256];       // first place of a digit in the sorted tile
@@ -114,7 +114,6 @@ rs_scatter_body(const unsigned long long* __restrict__ keys_in, const unsigned* 
     __shared__ unsigned sv[RS_TILE];
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
     for (int j = tid; j < 4 * 256; j += RS_THREADS) (&cnt[0][0])[j] = 0;
-    const unsigned goff = base[tid] + hist[(size_t)tid * nblk + blockIdx.x];
     __syncthreads();
     unsigned long long k[RS_ROUNDS];
     unsigned v[RS_ROUNDS], loc[RS_ROUNDS];
@@ -189,7 +188,7 @@ static __global__ void __launch_bounds__(RS_THREADS)
 k_rs_scatter(const unsigned long long* __restrict__ keys_in, const unsigned* __restrict__ vals_in, size_t n, int shift,
              const unsigned* __restrict__ hist, const unsigned* __restrict__ base, int nblk,
              unsigned long long* __restrict__ keys_out, unsigned* __restrict__ vals_out) {
-    rs_scatter_body(keys_in, vals_in, n, shift, hist, base, nblk, keys_out, vals_out);
+    rs_scatter_body(keys_in, vals_in, n, shift, base[threadIdx.x] + hist[(size_t)threadIdx.x * nblk + blockIdx.x], keys_out, vals_out);
 }
 
 // ---- the same sort driven from device memory ----------------------------------------------------------
@@ -198,6 +197,10 @@ k_rs_scatter(const unsigned long long* __restrict__ keys_in, const unsigned* __r
 // needed ones leave at once.  Pass p reads buffer p & 1 and writes the other one, so the result is in buffer
 // passes & 1.  Meant for at most a few hundred tiles: one block scans all 256 digit rows.
 struct RsCtl { unsigned n; int passes; };
+#ifndef PCP_RSD_ONE_KERNEL_TILES
+#define PCP_RSD_ONE_KERNEL_TILES 64
+#endif
+constexpr int RSD_ONE_KERNEL_TILES = PCP_RSD_ONE_KERNEL_TILES;   // up to this many tiles a pass is one kernel (k_rsd_pass)
 
 static __global__ void __launch_bounds__(RS_THREADS)
 k_rsd_hist(const RsCtl* __restrict__ ctl, int pass, unsigned long long* const k0, unsigned long long* const k1,
@@ -226,7 +229,47 @@ k_rsd_scatter(const RsCtl* __restrict__ ctl, int pass, unsigned long long* const
     const size_t n = (size_t)ctl->n;
     if ((size_t)blockIdx.x * RS_TILE >= n) return;
     const bool odd = pass & 1;
-    rs_scatter_body(odd ? k1 : k0, odd ? v1 : v0, n, 8 * pass, hist, base, nblk, odd ? k0 : k1, odd ? v0 : v1);
+    rs_scatter_body(odd ? k1 : k0, odd ? v1 : v0, n, 8 * pass, base[threadIdx.x] + hist[(size_t)threadIdx.x * nblk + blockIdx.x],
+                    odd ? k0 : k1, odd ? v0 : v1);
+}
+
+// A whole pass as one kernel, for a few tiles (the unknown points of one sweep): every block counts the digits of ALL keys
+// itself -- those of the tiles before its own and those from its own on, one LDS atomic per key, the keys come from L2 --
+// which gives it what the histogram and scan kernels would: where each digit starts (sum over all tiles of the smaller
+// digits) and how many keys of the digit the earlier tiles hold.  Same ranks, same places, one launch instead of three.
+static __global__ void __launch_bounds__(RS_THREADS)
+k_rsd_pass(const RsCtl* __restrict__ ctl, int pass, unsigned long long* const k0, unsigned long long* const k1,
+           unsigned* const v0, unsigned* const v1) {
+    __shared__ unsigned before[256], rest[256], s4[4];
+    if (pass >= ctl->passes) return;
+    const size_t n = (size_t)ctl->n;
+    const size_t tile0 = (size_t)blockIdx.x * RS_TILE;
+    if (tile0 >= n) return;
+    const bool odd = pass & 1;
+    const unsigned long long* __restrict__ kin = odd ? k1 : k0;
+    const int shift = 8 * pass;
+    before[threadIdx.x] = 0;
+    rest[threadIdx.x] = 0;
+    __syncthreads();
+    for (size_t j0 = 0; j0 < n; j0 += 8 * RS_THREADS) {          // eight loads in flight per thread
+        unsigned long long k[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const size_t j = j0 + (size_t)u * RS_THREADS + threadIdx.x;
+            k[u] = j < n ? kin[j] : 0ull;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const size_t j = j0 + (size_t)u * RS_THREADS + threadIdx.x;
+            const unsigned d = (unsigned)(k[u] >> shift) & 255u;
+            if (j < n) atomicAdd(j < tile0 ? &before[d] : &rest[d], 1u);
+        }
+    }
+    __syncthreads();
+    const unsigned mine = before[threadIdx.x] + rest[threadIdx.x];
+    unsigned total;
+    const unsigned start = block_scan256(mine, s4, total) - mine;
+    rs_scatter_body(kin, odd ? v1 : v0, n, shift, start + before[threadIdx.x], odd ? k0 : k1, odd ? v0 : v1);
 }
 
 // Enqueues max_passes passes over up to n_cap keys.
@@ -234,6 +277,11 @@ inline void radix_sort_pairs_dev(hipStream_t stream, const RsCtl* ctl, unsigned 
                                  unsigned* v1, size_t n_cap, int max_passes, unsigned* hist, unsigned* base) {
     const int nblk = (int)((n_cap + RS_TILE - 1) / RS_TILE);
     if (nblk == 0) return;
+    if (nblk <= RSD_ONE_KERNEL_TILES) {
+        for (int p = 0; p < max_passes; ++p)
+            hipLaunchKernelGGL(k_rsd_pass, dim3(nblk), dim3(RS_THREADS), 0, stream, ctl, p, k0, k1, v0, v1);
+        return;
+    }
     for (int p = 0; p < max_passes; ++p) {
         hipLaunchKernelGGL(k_rsd_hist, dim3(nblk), dim3(RS_THREADS), 0, stream, ctl, p, k0, k1, hist, nblk);
         hipLaunchKernelGGL(k_rsd_scan, dim3(1), dim3(256), 0, stream, ctl, p, hist, nblk, base);
