@@ -482,8 +482,8 @@ def extras(raws, device):
                                     "what": "CellGrid(refine=16): the search cell halved until an occupied cell holds <= 16 points"},
                      "roofline": {
                          "voxelize": roof(28.0 * len(cloud) + 16.0 * stored, fed[0], "the frame feed (k_feed_voxelize, k_voxel_stage, radix "
-                                          "sort of the unknown points, k_feed_new_voxels, k_feed_shift_old: 26 launches per sweep)",
-                                          "launch latency: 10 sweeps of 100 k points, each a chain of 26 small dependent kernels "
+                                          "sort of the unknown points, k_feed_new_voxels, k_feed_shift_old: 14 launches per sweep)",
+                                          "launch latency: 10 sweeps of 100 k points, each a chain of 14 small dependent kernels "
                                           "(profiles/r03_voxel_kernel_stats.csv); 28 B per point + 16 B per voxel is what the feed must move"),
                          "morton_sort": roof(24.0 * len(cloud) * info["sort_passes"], sort_s, "k_rsd_hist / k_rsd_scan / k_rsd_scatter per "
                                              "8-bit digit", "1 M keys: a pass is 3 launches of a few microseconds each; the scatter's 128-B runs "
