@@ -3,22 +3,24 @@
     python bench.py --gpus N --steps K --warmup W
 
 Workload `sequence` (default): frame-to-frame odometry over real consecutive KITTI sweeps
-(2011_09_26 drive, frames 0000000000 ... 0000000011 of the reference's sample_data, held as fixtures;
+(2011_09_26 drive, all thirty frames 0000000000 ... 0000000029 of the reference's sample_data, held as fixtures;
 walked forwards and backwards so that every pair is a consecutive one).  One STEP = every rank registers
 a run of --pairs + 1 raw frames = --pairs consecutive pairs by point-to-plane ICP with ring normals,
 at most 10 iterations, stop at mean|dx| < 1e-6 (PointcloudIcpContainer.full_pt2pl as UI.py:400 calls
 it), starting from the raw velodyne records in page-locked HOST memory: the timed region holds the
 upload of every frame (copy stream, overlapped with the previous step's kernels), decode + ego filter
 + rotation, ring segmentation, unit vectors, ring bands, normals, the whole iteration loop of every
-pair and the fetch of the solved steps.  Nothing of a step is resident beforehand.
+pair, the pose of every pair (tracking grid + Kabsch on the device) and the fetch of steps and poses.  Nothing of a
+step is resident beforehand.
 Pairs are independent, so ranks share nothing: weak scaling, no collective in the data path
 (torch.distributed only supplies the barrier and the max).
 
-Workload `moved-copy` is the previous round's configs[1] substitute (frame 0 against rigidly moved +
+Workload `moved-copy` is an earlier configs[1] substitute (frame 0 against rigidly moved +
 noise copies, inputs resident), kept for comparison.
 
-Extra objects on the line (N = 1 only): `nn` (stand-alone NearestNeighbourScan), `pt2pt20` (configs[0]),
-`voxel_sweep` (configs[2]), `single_pair` (latency of one registration).
+Extra objects on the line (N = 1 only): `odometry_e2e` (the driver's chained loop on the device beside the host-driven
+one), `nn` (stand-alone NearestNeighbourScan), `pt2pt20` (configs[0]), `ringless_pt2pl` (configs[1] without scan rings),
+`voxel_sweep` (configs[2]), `single_pair` (latency of one registration), `imu_guess`; for N > 1 `scan_to_map` (configs[4]).
 """
 import argparse
 import ctypes as C
