@@ -1,4 +1,4 @@
-# Round-2 profile summaries in one GPU call (written under gpurun_out/prof2, copied into profiles/ by hand):
+# The profiles/r02_* summaries in one GPU call (written under gpurun_out/prof2, copied into profiles/ by hand):
 # bench line, kernel trace stats, FETCH_SIZE and WRITE_SIZE passes (separate runs) + their calibration on
 # known byte counts, SQ / TA / L2 counter passes of the bench's sequence workload.
 set -e

@@ -1,4 +1,4 @@
-# Round-3 profile summaries in one GPU call (written under gpurun_out/prof3, copied into profiles/ by hand):
+# The profiles/r03_* summaries in one GPU call (written under gpurun_out/prof3, copied into profiles/ by hand):
 # bench line; kernel trace stats of the headline workload, of the device chain, of the voxel sweep, of the cell grid and of
 # the stand-alone NN calls; FETCH_SIZE / WRITE_SIZE passes (separate runs) with their calibration; SQ / TA / L2 passes.
 set -e
