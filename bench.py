@@ -275,7 +275,7 @@ class Pair:
 
 
 def run_moved_copy(args, rank, world, device, barrier):
-    """The previous round's workload: KITTI frame 0 against R*frame + t + N(0, 1 cm) copies of itself; target, scan
+    """The moved-copy workload: KITTI frame 0 against R*frame + t + N(0, 1 cm) copies of itself; target, scan
     lines and float64 source resident before the timed region; one step = batched prepare + batched loop."""
     raws, source = real_frames()
     a = lidar.frame_from_raw(raws[0][:, :3])
