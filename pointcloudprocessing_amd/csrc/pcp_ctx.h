@@ -28,6 +28,7 @@ struct pcp_ctx {
     float4 *a = nullptr, *ua = nullptr, *normals = nullptr, *b32 = nullptr;
     double *b_in = nullptr, *b64 = nullptr;
     float* hint = nullptr;
+    int hinted_upto = 0;               // source points [0, hinted_upto) have been searched since the hints were last reset
     uint32_t* nn_idx = nullptr;        // 2 max_points words: the indices of the last search, its squared distances behind them
     int2* scan = nullptr;
     int2* scan_host = nullptr;     // page-locked staging of the scan-line table (max_scans rows)

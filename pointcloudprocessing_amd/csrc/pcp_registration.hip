@@ -805,6 +805,10 @@ int launch_first_rings(pcp_ctx* c) {
         return (v == 4 || v == 8 || v == 16 || v == 32) ? v : (v == 0 ? 0 : 8);
     }();
     if (!lanes) return 0;
+    // every source point up to hinted_upto has been through a search since the hints were last reset: nothing for the
+    // pre-pass to do (a point that came out of it without a ring keeps -1 and walks all rings in the search kernel)
+    if (c->n_b <= c->hinted_upto) return 0;
+    c->hinted_upto = c->n_b;
     const LsArgs A = ls_args(c, 0, nullptr);
     const dim3 grid(cdiv(c->n_b * lanes, PCP_BLOCK)), block(PCP_BLOCK);
     const size_t sm = scan_smem(c);
@@ -976,6 +980,7 @@ int pcp_synchronize(pcp_ctx* c) {
 int pcp_reset_hints(pcp_ctx* c) {
     if (int e = use(c)) return e;
     hipLaunchKernelGGL(k_fill, dim3(cdiv(c->max_points, 256)), dim3(256), 0, c->stream, c->hint, c->max_points, -1.0f);
+    c->hinted_upto = 0;
     PCP_CHECK(hipGetLastError());
     return 0;
 }
@@ -1466,6 +1471,7 @@ int pcp_batch_prepare(pcp_batch* b, int with_normals) {
         PrepArgs P;
         memset(&P, 0, sizeof(P));
         P.a = c->a; P.ua = c->ua; P.normals = c->normals; P.scan = c->scan; P.stat = c->ring_stat; P.bins = c->ring_bins; P.hint = c->hint;
+        c->hinted_upto = 0;                  // k_unit_batch resets the hints
         P.n_a = c->n_a; P.Z = c->n_scans; P.max_points = c->max_points; P.o = c->origin;
         want[i] = P;
         max_na = c->n_a > max_na ? c->n_a : max_na;
