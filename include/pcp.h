@@ -618,7 +618,9 @@ int pcp_chain_reset(pcp_chain* chain);
  * frames continue from the device's own count and from the points fed so far); first_voxel_serial (or NULL) receives
  * the first frame's ticket for pcp_voxel_add_wait, the others follow consecutively.  The call waits once, for the number of points each frame keeps
  * (returned in n_points, n_frames ints, may be NULL), then enqueues and returns a ticket; at most two submissions may
- * be in flight.  Raw buffers must stay valid until the ticket is collected. */
+ * be in flight.  Raw buffers must stay valid until the ticket is collected.  A call that fails while it enqueues (the
+ * voxel feed refuses a frame, a launch fails) drains its streams and forgets the drive as pcp_chain_reset does: the
+ * frames since the last collected submission are lost, the next frame submitted starts a new drive. */
 int pcp_chain_submit(pcp_chain* chain, const float* const* raw_xyzi, const int* n_raw, int n_frames, float min_range,
                      const double* R9, const double* imu, int mode, int iterations, float tol, int closing_iterations,
                      int reset_every, pcp_ctx* voxel_ctx, float voxel_size, int voxel_stored, int voxel_begin_index,

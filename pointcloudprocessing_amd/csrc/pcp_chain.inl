@@ -411,16 +411,25 @@ int pcp_chain_submit(pcp_chain* s, const float* const* raw_xyzi, const int* n_ra
         vox_begin += n;
         return 0;
     };
+    // A failure from here on leaves frames of this submission half enqueued: the streams are drained and the drive is
+    // forgotten (as pcp_chain_reset does), so that nothing later builds on positions that were never reported.
+    auto give_up = [&](int code) -> int {
+        (void)hipStreamSynchronize(q);
+        if (voxel_ctx) (void)hipStreamSynchronize(voxel_ctx->stream);
+        s->total_frames = 0; s->local_frames = 0; s->n_reference = 0; s->mode = -1;
+        pcp_append_error(" (the drive has been reset: its frames since the last collected submission are lost)");
+        return code;
+    };
     for (int f = 0; f < F; ++f) {
         const int n = (int)kept[f];
         ChainRecord* rec = s->rec_dev[slot] + f;
         if (s->total_frames == 0) {
             // the first frame of a drive: its cloud, turned by the IMU attitude, is the first reference (:168-189)
             hipLaunchKernelGGL(k_chain_begin, dim3(1), dim3(1), 0, q, s->state);
-            if (int e = chain_retarget(s, s->xyz[slot][f], n, mode)) return e;
+            if (int e = chain_retarget(s, s->xyz[slot][f], n, mode)) return give_up(e);
             hipLaunchKernelGGL(k_chain_first_record, dim3(1), dim3(64), 0, q, s->state, n, rec);
             PCP_CHECK(hipGetLastError());
-            if (int e = feed(s->xyz[slot][f], n)) return e;
+            if (int e = feed(s->xyz[slot][f], n)) return give_up(e);
             s->cloud_of[slot][f] = s->xyz[slot][f];
             s->total_frames = 1;
             s->local_frames = 0;
@@ -445,11 +454,11 @@ int pcp_chain_submit(pcp_chain* s, const float* const* raw_xyzi, const int* n_ra
         hipLaunchKernelGGL(k_chain_refine, dim3(cdiv(n, 256)), dim3(256), 0, q, c->b_in, n, c->pose, s->state, c->state, c->dx_trace,
                            s->refined[slot][f], rec, closing ? 1 : 0);
         PCP_CHECK(hipGetLastError());
-        if (int e = feed(s->refined[slot][f], n)) return e;
+        if (int e = feed(s->refined[slot][f], n)) return give_up(e);
         s->cloud_of[slot][f] = s->refined[slot][f];
         s->local_frames++;
         if (closing) {                                                      // :250-254
-            if (int e = chain_retarget(s, s->refined[slot][f], n, mode)) return e;
+            if (int e = chain_retarget(s, s->refined[slot][f], n, mode)) return give_up(e);
             s->local_frames = 0;
         }
         s->total_frames++;

@@ -4,6 +4,8 @@
 
 // Records a printf-style message as the calling thread's last error; returns 1.
 int pcp_fail(const char* fmt, ...) __attribute__((format(printf, 1, 2)));
+// Appends to the calling thread's last error (what a caller up the stack did about it).
+void pcp_append_error(const char* text);
 
 #define PCP_CHECK(expr)                                                                      \
     do {                                                                                     \

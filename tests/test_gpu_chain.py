@@ -154,3 +154,36 @@ def test_chain_reports_a_reference_it_cannot_prepare():
             assert np.array_equal(fa[1], fb[1]) and np.array_equal(bits(fa[4]), bits(fb[4]))
     finally:
         point.close()
+
+
+def test_a_submission_that_fails_half_way_resets_the_drive():
+    """The voxel feed refuses the first frame (a voxel count the map does not hold): the frames already enqueued are
+    drained, the drive starts over with the next submission, and that one gives what a fresh chain gives."""
+    from pointcloudprocessing_amd import PcpError
+    raws = [_raw4(r) for r in kitti_all_raw()[:3]]
+    rows = np.tile(np.concatenate([np.eye(3).reshape(9), np.zeros(3)]), (3, 1))
+    cs = ComputeShader(maxPointsPerCloud=200000, maxScans=100)
+    vox = Voxelizer(cs, None)
+    vox.separate_colors, vox.filter_outliers = False, False
+    vox.init(0.5)
+
+    class WrongCount:                       # a voxelizer that claims five voxels the resident table does not have
+        def _feed_begin(self):
+            ctx, size, stored, begin, width, filt = vox._feed_begin()
+            return ctx, size, 5, begin, width, filt
+
+    chain, fresh = OdometryChain(max_frames=3), OdometryChain(max_frames=3)
+    try:
+        good = chain.collect(chain.submit(raws[:1], rows[:1]))                    # frame 0 of a drive
+        with pytest.raises(PcpError, match="resident table has 0 rows.*the drive has been reset"):
+            chain.submit(raws[1:], rows[1:], voxelizer=WrongCount())
+        again = chain.collect(chain.submit(raws, rows))                          # frame 0 of a new drive
+        want = fresh.collect(fresh.submit(raws, rows))
+        assert len(good) == 1 and len(again) == 3
+        for fa, fb in zip(again, want):
+            assert np.array_equal(fa[1], fb[1]) and np.array_equal(bits(fa[4]), bits(fb[4]))
+    finally:
+        chain.close()
+        fresh.close()
+        vox.cleanup()
+        cs.cleanup()
