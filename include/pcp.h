@@ -398,6 +398,13 @@ int pcp_grid_append_slab_dev(pcp_grid* grid, const double* xyz_dev, size_t n, do
  * being collected every call that reads or rebuilds the map fails; batches may not carry normals. */
 int pcp_grid_collect_begin(pcp_grid* grid);
 int pcp_grid_collect_end(pcp_grid* grid);
+/* The same without a bracket to close: while on, every append (without normals) waits as if collected, and the first call
+ * that reads the map -- a query, a registration, pcp_grid_info, pcp_grid_sorted_ids, normals -- takes everything that waits
+ * in first, in one merge.  For a map that is fed every frame and read now and then (the Voxelizer's per-frame hand-off,
+ * Voxelizer.py:130-133): an append then costs a copy, and the O(map) merge is paid once per reader.  A rebuild drops what
+ * waits with the map it replaces; an append that carries normals takes the waiting batches in first; switching off flushes.
+ * pcp_grid_collect_begin adopts what waits, and its pcp_grid_collect_end flushes as always. */
+int pcp_grid_defer_appends(pcp_grid* grid, int on);
 /* Facts about the last build: points, occupied cells, extent in cells, radix
  * passes, device time of the whole build and of the sort alone (ms). Any pointer may be NULL. */
 int pcp_grid_info(pcp_grid* grid, unsigned long long* n_points, unsigned long long* n_cells, int* extent3,

@@ -84,6 +84,7 @@ SIGNATURES = {
                                        C.POINTER(C.c_size_t)]),
     "pcp_grid_collect_begin": (C.c_int, [C.c_void_p]),
     "pcp_grid_collect_end": (C.c_int, [C.c_void_p]),
+    "pcp_grid_defer_appends": (C.c_int, [C.c_void_p, C.c_int]),
     "pcp_grid_append_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_longlong]),
     "pcp_grid_append_slab_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_double, C.c_ulonglong, C.c_ulonglong,
                                            C.c_longlong, C.POINTER(C.c_size_t)]),

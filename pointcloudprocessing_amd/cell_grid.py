@@ -112,6 +112,11 @@ class CellGrid:
                 check(self._lib.pcp_grid_collect_end(self._g))
         return _collect()
 
+    def defer_appends(self, on=True):
+        """While on, appends wait on the device and join the map, all at once, when it is next read
+        (pcp_grid_defer_appends): an append costs a copy, the merge is paid once per reader."""
+        check(self._lib.pcp_grid_defer_appends(self._g, int(bool(on))))
+
     def append_device(self, xyz_dev, n, first_id=None, slab=None):
         """append() for n points that already lie in this device's memory as n x 3 float64 (xyz_dev: address, e.g.
         from ComputeShader.stagedPointsDevice); whatever produced them must have completed."""

@@ -1041,6 +1041,8 @@ struct pcp_grid {
     // frame would otherwise allocate and free nine buffers per append
     // appends collected between pcp_grid_collect_begin and pcp_grid_collect_end: coordinates and ids of the points waiting
     bool collecting = false;
+    bool deferred = false;           // appends wait (as between collect_begin and collect_end) until somebody reads the map
+    bool implicit = false;           // the collection under way was begun by a deferred append, not by the caller
     double* pend_xyz = nullptr; long long* pend_id = nullptr; size_t pend_n = 0, pend_cap = 0;
     void* scr[9] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     size_t scr_bytes[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -1140,12 +1142,17 @@ int reserve_source(pcp_grid* g, size_t m) {
     return 0;
 }
 
-int check_collecting(const pcp_grid* g) {
+int flush_collected(pcp_grid* g);
+
+// Every call that reads or rebuilds the map starts here: batches that deferred appends left waiting join the map now;
+// a collection the caller began must be ended by the caller.
+int check_collecting(pcp_grid* g) {
+    if (g->collecting && g->implicit) return flush_collected(g);
     if (g->collecting) return pcp_fail("appends are being collected: the map is not complete before pcp_grid_collect_end");
     return 0;
 }
 
-int check_source(const pcp_grid* g) {
+int check_source(pcp_grid* g) {
     if (!g) return pcp_fail("null grid");
     if (check_collecting(g)) return 1;
     if (g->m == 0) return pcp_fail("no source cloud uploaded (pcp_grid_source)");
@@ -1481,6 +1488,14 @@ static int append_device(pcp_grid* g, const double* d_xyz, const float4* d_nrm, 
                          const long long* abs_ids = nullptr) {
     hipStream_t s = g->stream;
     if (m == 0) return 0;
+    if (g->collecting && g->implicit && d_nrm && !abs_ids) {       // normals cannot wait: what waits goes in first
+        if (flush_collected(g)) return 1;
+    }
+    if (g->deferred && !g->collecting && !d_nrm && !abs_ids) {
+        g->collecting = true;
+        g->implicit = true;
+        g->pend_n = 0;
+    }
     if (g->collecting && !abs_ids) {
         // the batch waits: coordinates and ids go behind what is waiting already (this stream; the caller's buffer is free
         // again once the stream has passed the copy, which the caller's next wait on the grid covers)
@@ -1566,6 +1581,20 @@ static int append_device(pcp_grid* g, const double* d_xyz, const float4* d_nrm, 
     return 0;
 }
 
+namespace {
+int flush_collected(pcp_grid* g) {
+    PCP_CHECK(hipSetDevice(g->device));
+    g->collecting = false;
+    g->implicit = false;
+    const size_t m = g->pend_n;
+    g->pend_n = 0;
+    if (m == 0) return 0;
+    // one sort, one merge and one cell table for everything that waited: the map an append per batch would have left
+    // (a cell's points in the order of their ids) as long as the batches' ids ascend, as they do for appends in general
+    return append_device(g, g->pend_xyz, nullptr, nullptr, 0, m, g->pend_id);
+}
+}  // namespace
+
 static int check_build_args(pcp_grid* g, const double* xyz, size_t n, double cell) {
     if (!g) return pcp_fail("null grid");
     if (!(cell > 0.0) || !std::isfinite(cell)) return pcp_fail("cell size must be positive and finite");
@@ -1576,6 +1605,7 @@ static int check_build_args(pcp_grid* g, const double* xyz, size_t n, double cel
 
 int pcp_grid_build(pcp_grid* g, const double* xyz, size_t n, double cell, const float* normals_xyzw) {
     if (check_build_args(g, xyz, n, cell)) return 1;
+    if (g->collecting && g->implicit) { g->collecting = false; g->implicit = false; g->pend_n = 0; }   // replaced with the map
     if (check_collecting(g)) return 1;
     PCP_CHECK(hipSetDevice(g->device));
     hipStream_t s = g->stream;
@@ -1602,6 +1632,7 @@ int pcp_grid_build(pcp_grid* g, const double* xyz, size_t n, double cell, const 
 int pcp_grid_build_slab(pcp_grid* g, const double* xyz, size_t n, double cell, const float* normals_xyzw,
                         double own_cell, unsigned long long lo, unsigned long long hi, size_t* n_kept) {
     if (check_build_args(g, xyz, n, cell)) return 1;
+    if (g->collecting && g->implicit) { g->collecting = false; g->implicit = false; g->pend_n = 0; }   // replaced with the map
     if (check_collecting(g)) return 1;
     if (!(own_cell > 0.0)) return pcp_fail("partition cell size must be positive");
     if (lo > hi) return pcp_fail("owned key range is empty");
@@ -1722,23 +1753,24 @@ static int append_host(pcp_grid* g, const double* xyz, size_t n, const float* no
 int pcp_grid_collect_begin(pcp_grid* g) {
     if (!g) return pcp_fail("null grid");
     if (!(g->cell > 0.0)) return pcp_fail("the grid has no cell size yet: call pcp_grid_build first (an empty map will do)");
-    if (g->collecting) return pcp_fail("appends are being collected already");
-    g->collecting = true;
-    g->pend_n = 0;
+    if (g->collecting && !g->implicit) return pcp_fail("appends are being collected already");
+    if (!g->collecting) g->pend_n = 0;
+    g->collecting = true;            // batches deferred so far stay in the collection, which is the caller's to end now
+    g->implicit = false;
     return 0;
 }
 
 int pcp_grid_collect_end(pcp_grid* g) {
     if (!g) return pcp_fail("null grid");
     if (!g->collecting) return pcp_fail("no appends are being collected");
-    PCP_CHECK(hipSetDevice(g->device));
-    g->collecting = false;
-    const size_t m = g->pend_n;
-    g->pend_n = 0;
-    if (m == 0) return 0;
-    // one sort, one merge and one cell table for everything that waited: the map an append per batch would have left
-    // (a cell's points in the order of their ids) as long as the batches' ids ascend, as they do for appends in general
-    return append_device(g, g->pend_xyz, nullptr, nullptr, 0, m, g->pend_id);
+    return flush_collected(g);
+}
+
+int pcp_grid_defer_appends(pcp_grid* g, int on) {
+    if (!g) return pcp_fail("null grid");
+    if (!on && g->collecting && g->implicit && flush_collected(g)) return 1;
+    g->deferred = on != 0;
+    return 0;
 }
 
 int pcp_grid_append(pcp_grid* g, const double* xyz, size_t n, const float* normals_xyzw, long long first_id) {

@@ -12,12 +12,16 @@ import numpy as np
 class MapSink:
     needs_renderer = False            # Voxelizer._hand_off feeds it without a renderer
 
-    def __init__(self, target, compute=None):
+    def __init__(self, target, compute=None, defer=True):
         """target: a CellGrid (append) or a scan_to_map.MapRegistration (ingest: routed by key range).
         compute: the Voxelizer's ComputeShader, when it is on the target's device -- the staged voxels are then
         resolved to points and appended on the device (a device copy of the point store is switched on; do this
-        before the map's first addPoints), and frameVoxelized is not used."""
+        before the map's first addPoints), and frameVoxelized is not used.
+        defer: the per-frame batches wait on the device and join the map when it is next read (CellGrid.defer_appends)."""
         self.target = target
+        grid = self._grid()
+        if defer and grid is not None and hasattr(grid, "defer_appends"):
+            grid.defer_appends(True)
         self._batch = []
         self.points_fed = 0
         self.voxels_fed = 0
@@ -38,10 +42,15 @@ class MapSink:
         self.voxels_fed += rows
         return n
 
+    def _grid(self):
+        if hasattr(self.target, "collect"):
+            return self.target
+        return getattr(getattr(self.target, "backend", None), "grid", None)
+
     def collecting(self):
         """Context manager for a producer that hands over many batches in a row (Voxelizer.stageAllRemaningVoxels): the
         map takes them all in at the end, in one merge (CellGrid.collect)."""
-        grid = self.target if hasattr(self.target, "collect") else getattr(getattr(self.target, "backend", None), "grid", None)
+        grid = self._grid()
         if self.compute is None or grid is None or not hasattr(grid, "collect"):
             import contextlib
             return contextlib.nullcontext()

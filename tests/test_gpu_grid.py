@@ -394,6 +394,39 @@ def test_collected_appends_equal_appends_one_by_one(frames):
         g_col.cleanup()
 
 
+def test_deferred_appends_join_the_map_when_it_is_read(frames):
+    """pcp_grid_defer_appends: batches wait on the device; the first reader takes them in, all at once -- the map an append per
+    batch leaves.  A collection the caller opens adopts what waits; a rebuild drops it with the map."""
+    a, b = frames
+    batches = [b[:40000] + np.array([0.3, 0.0, 0.1]), b[40000:40007], a[::3] * np.array([1.0, 1.0, -1.0]),
+               b[:5000] + np.array([-700.0, 35.0, 900.0])]
+    g_one, g_def = CellGrid(a, cell=0.5), CellGrid(a, cell=0.5)
+    try:
+        g_def.defer_appends(True)
+        for extra in batches[:2]:
+            g_one.append(extra)
+            g_def.append(extra)
+        _same_grid(g_one, g_def, b[::11])                          # info() / query() inside are the readers that flush
+        g_one.append(batches[2])
+        g_def.append(batches[2])
+        with g_def.collect():                                      # adopts the batch that waits
+            g_def.append(batches[3])
+        g_one.append(batches[3])
+        _same_grid(g_one, g_def, np.concatenate([b[::13], batches[3][::7] + 0.05]))
+        g_def.append(b[:100] + 5.0)                                # waits ...
+        g_def.rebuild(a, cell=0.5)                                 # ... and goes with the map it was meant for
+        g_one.rebuild(a, cell=0.5)
+        _same_grid(g_one, g_def, b[::17])
+        g_def.append(batches[0])
+        g_def.defer_appends(False)                                 # switching off flushes
+        g_one.append(batches[0])
+        assert g_def.info()["points"] == g_one.info()["points"] == len(a) + len(batches[0])
+        _same_grid(g_one, g_def, b[::19])
+    finally:
+        g_one.cleanup()
+        g_def.cleanup()
+
+
 def test_appending_with_normals_and_the_rules_around_them(frames):
     a, b = frames[0][::5], frames[1][::5]
     rng = np.random.default_rng(2)
