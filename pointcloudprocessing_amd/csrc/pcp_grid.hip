@@ -1044,8 +1044,9 @@ struct pcp_grid {
     bool deferred = false;           // appends wait (as between collect_begin and collect_end) until somebody reads the map
     bool implicit = false;           // the collection under way was begun by a deferred append, not by the caller
     double* pend_xyz = nullptr; long long* pend_id = nullptr; size_t pend_n = 0, pend_cap = 0;
-    void* scr[9] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    size_t scr_bytes[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    static constexpr int n_scr = 16;          // 0-8: a sorted run (sort_run); 9-15: staging of a build's input
+    void* scr[n_scr] = {};
+    size_t scr_bytes[n_scr] = {};
     // map
     size_t n = 0, cap = 0;
     double cell = 0.0;
@@ -1063,6 +1064,7 @@ struct pcp_grid {
     Cell* table = nullptr;
     int log_cap = 0;
     size_t table_cap = 0;
+    size_t table_alloc = 0;                  // entries the table's allocation holds (>= table_cap)
     unsigned long long n_cells = 0;
     int sort_passes = 0;
     float build_ms = 0.0f, sort_ms = 0.0f;
@@ -1103,7 +1105,7 @@ int free_map(pcp_grid* g) {
     void* p[] = {g->pts, g->normals, g->keys, g->pts_alt, g->normals_alt, g->keys_alt, g->table};
     for (void* q : p) if (q) PCP_CHECK(hipFree(q));
     g->pts = g->pts_alt = nullptr; g->normals = g->normals_alt = nullptr; g->keys = g->keys_alt = nullptr; g->table = nullptr;
-    g->cap = g->cap_alt = 0; g->table_cap = 0; g->n = 0; g->log_cap = 0;
+    g->cap = g->cap_alt = 0; g->table_cap = 0; g->table_alloc = 0; g->n = 0; g->log_cap = 0;
     return 0;
 }
 
@@ -1433,12 +1435,15 @@ static int install_table(pcp_grid* g) {
     g->n_cells = cells;
     int log_cap = 4;
     while ((1ull << log_cap) < 2 * cells) ++log_cap;
-    if (!g->table || log_cap != g->log_cap) {
+    // the table's size follows the rule; its allocation only grows (a smaller table lives in the front of a larger one)
+    g->log_cap = log_cap;
+    g->table_cap = (size_t)1 << log_cap;
+    if (!g->table || g->table_cap > g->table_alloc) {
         if (g->table) PCP_CHECK(hipFree(g->table));
         g->table = nullptr;
-        g->log_cap = log_cap;
-        g->table_cap = (size_t)1 << log_cap;
+        g->table_alloc = 0;
         PCP_CHECK(hipMalloc(&g->table, g->table_cap * sizeof(Cell)));
+        g->table_alloc = g->table_cap;
     }
     PCP_CHECK(hipMemsetAsync(g->table, 0xFF, g->table_cap * sizeof(Cell), s));
     hipLaunchKernelGGL(k_insert_cells, dim3(blocks_for(g->n, 256)), dim3(256), 0, s, g->keys, g->n, g->table, g->log_cap);
@@ -1454,9 +1459,57 @@ static void set_bounds(pcp_grid* g, const int lo[3], const int hi[3]) {
     }
 }
 
+// Up to this many points a build sorts in the grid's scratch and copies the result into map buffers it keeps from
+// build to build (a build then allocates nothing once the buffers are large enough: allocation and release were most
+// of a 1 M-point build's time); larger maps hand the sorted run's own buffers over and keep no scratch.
+constexpr size_t GRID_POOLED_BUILD = (size_t)1 << 24;
+
+static int build_device_pooled(pcp_grid* g, const double* d_xyz, const float4* d_nrm, const unsigned* d_ids, size_t n, double cell) {
+    hipStream_t s = g->stream;
+    g->n = 0;
+    g->cell = cell;
+    g->have_normals = d_nrm != nullptr;
+    g->normals_estimated = false;
+    g->n_cells = 0;
+    g->sort_passes = 0;
+    g->ext[0] = g->ext[1] = g->ext[2] = 0;
+    g->nn_valid = false;
+    if (!d_nrm)                                     // a map without normals holds no buffers for them
+        for (float4** q : {&g->normals, &g->normals_alt}) { if (*q) PCP_CHECK(hipFree(*q)); *q = nullptr; }
+    if (n == 0) return 0;
+    SortedRun run;
+    if (sort_run(g, d_xyz, d_nrm, d_ids, 0, n, cell, true, &run, true)) return 1;
+    if (g->cap < n || (d_nrm && !g->normals)) {
+        for (void* q : {(void*)g->pts, (void*)g->keys, (void*)g->normals}) if (q) PCP_CHECK(hipFree(q));
+        g->pts = nullptr; g->keys = nullptr; g->normals = nullptr; g->cap = 0;
+        hipError_t e = hipMalloc(&g->pts, n * sizeof(GridPoint));
+        if (e == hipSuccess) e = hipMalloc(&g->keys, n * 8);
+        if (e == hipSuccess && d_nrm) e = hipMalloc(&g->normals, n * 16);
+        if (e != hipSuccess) return pcp_fail("buffers for a map of %zu points: %s", n, hipGetErrorString(e));
+        g->cap = n;
+    }
+    PCP_CHECK(hipMemcpyAsync(g->pts, run.pts, n * sizeof(GridPoint), hipMemcpyDeviceToDevice, s));
+    PCP_CHECK(hipMemcpyAsync(g->keys, run.keys, n * 8, hipMemcpyDeviceToDevice, s));
+    if (d_nrm) PCP_CHECK(hipMemcpyAsync(g->normals, run.normals, n * 16, hipMemcpyDeviceToDevice, s));
+    g->n = n;
+    g->sort_passes = run.passes;
+    set_bounds(g, run.lo, run.hi);
+    if (install_table(g)) { g->n = 0; return 1; }
+    PCP_CHECK(hipEventRecord(g->ev3, s));
+    PCP_CHECK(hipStreamSynchronize(s));
+    PCP_CHECK(hipEventElapsedTime(&g->build_ms, g->ev0, g->ev3));
+    PCP_CHECK(hipEventElapsedTime(&g->sort_ms, g->ev1, g->ev2));
+    return 0;
+}
+
 static int build_device(pcp_grid* g, const double* d_xyz, const float4* d_nrm, const unsigned* d_ids, size_t n, double cell) {
+    if (n <= GRID_POOLED_BUILD) return build_device_pooled(g, d_xyz, d_nrm, d_ids, n, cell);
     hipStream_t s = g->stream;
     if (free_map(g)) return 1;
+    for (int k = 0; k < pcp_grid::n_scr; ++k) {       // a map this large keeps no scratch of its own size around
+        if (g->scr[k]) PCP_CHECK(hipFree(g->scr[k]));
+        g->scr[k] = nullptr; g->scr_bytes[k] = 0;
+    }
     g->cell = cell;
     g->have_normals = d_nrm != nullptr;
     g->normals_estimated = false;
@@ -1613,19 +1666,22 @@ int pcp_grid_build(pcp_grid* g, const double* xyz, size_t n, double cell, const 
     double* d_xyz = nullptr;
     float4* d_nrm = nullptr;
     int rc = 0;
+    const bool pooled = n <= GRID_POOLED_BUILD;      // the input waits in the grid's scratch, which stays
     if (n) {
-        hipError_t e = hipMalloc(&d_xyz, n * 24);
+        hipError_t e = pooled ? grid_scratch(g, 9, n * 24, (void**)&d_xyz) : hipMalloc(&d_xyz, n * 24);
         if (e == hipSuccess) e = hipMemcpyAsync(d_xyz, xyz, n * 24, hipMemcpyHostToDevice, s);
         if (e == hipSuccess && normals_xyzw) {
-            e = hipMalloc(&d_nrm, n * 16);
+            e = pooled ? grid_scratch(g, 10, n * 16, (void**)&d_nrm) : hipMalloc(&d_nrm, n * 16);
             if (e == hipSuccess) e = hipMemcpyAsync(d_nrm, normals_xyzw, n * 16, hipMemcpyHostToDevice, s);
         }
         if (e != hipSuccess) rc = pcp_fail("uploading the map failed: %s", hipGetErrorString(e));
     }
     if (!rc) rc = build_device(g, d_xyz, d_nrm, nullptr, n, cell);
     if (!rc) g->id_end = (long long)n;
-    if (d_xyz) (void)hipFree(d_xyz);
-    if (d_nrm) (void)hipFree(d_nrm);
+    if (!pooled) {
+        if (d_xyz) (void)hipFree(d_xyz);
+        if (d_nrm) (void)hipFree(d_nrm);
+    }
     return rc;
 }
 
