@@ -61,6 +61,9 @@ __device__ __forceinline__ float4 unit_sphere(const float4 p, const float4 o) {
 #ifndef PCP_WRAP_GROUP
 #define PCP_WRAP_GROUP 4          // the same for a window that wraps around its ring's end (each slot needs its own index)
 #endif
+#ifndef PCP_SCALAR_LEVELS
+#define PCP_SCALAR_LEVELS 1       // search levels at which the whole wave stands at one place read it through the scalar cache
+#endif
 #define PCP_AZ_BINS 64            // azimuth bins of the per-ring elevation table
 // 0.999 * (sin(0.99 * 2 pi / PCP_AZ_BINS) - 1e-5)^2, rounded down: squared sine of the smallest
 // azimuth gap between a query and a target point two or more bins away, with the margins of
@@ -114,6 +117,15 @@ __device__ __forceinline__ void search_level(const Target& T, const float4 ref, 
         const int i2 = (idx + 1 == L) ? 0 : idx + 1;
         c1 = dot4(ld4i(T.ua, beg + i1), ref) + 1.0f;
         c2 = dot4(ld4i(T.ua, beg + i2), ref) + 1.0f;
+    } else if (PCP_SCALAR_LEVELS && __all(beg + idx == __builtin_amdgcn_readfirstlane(beg + idx))) {
+        // every lane of the wave stands at the same place of the same ring (the first levels of neighbouring queries on
+        // one ring): the two neighbours are read once, through the scalar cache, instead of by a 64-lane gather
+        typedef const pcp_f4 __attribute__((address_space(4)))* cf4_t;
+        const cf4_t m = (cf4_t)(const void*)((const char PCP_GLOBAL*)T.ua + ((size_t)(unsigned)__builtin_amdgcn_readfirstlane(beg + idx) << 4));
+        const pcp_f4 v1 = m[-1], v2 = m[1];
+        c1 = dot4(make_float4(v1.x, v1.y, v1.z, v1.w), ref) + 1.0f;
+        asm volatile("" : "+v"(c1));
+        c2 = dot4(make_float4(v2.x, v2.y, v2.z, v2.w), ref) + 1.0f;
     } else {                                      // both neighbours sit beside idx: one address
         const gf4_t m = (gf4_t)((const char PCP_GLOBAL*)T.ua + ((unsigned)(beg + idx) << 4));
         const pcp_f4 v1 = m[-1], v2 = m[1];
@@ -268,9 +280,17 @@ __device__ __forceinline__ void ring_windows(const Target& T, const float4 q, co
         } else {                                      // both neighbours sit beside idx: one address per ring
 #pragma unroll
             for (int k = 0; k < N; ++k) {
-                const gf4_t m = (gf4_t)((const char PCP_GLOBAL*)T.ua + ((unsigned)(se[k].x + idx[k]) << 4));
-                v1[k] = m[-1];
-                v2[k] = m[1];
+                const int pos = se[k].x + idx[k];
+                if (PCP_SCALAR_LEVELS && __all(pos == __builtin_amdgcn_readfirstlane(pos))) {    // as in search_level
+                    typedef const pcp_f4 __attribute__((address_space(4)))* cf4_t;
+                    const cf4_t m = (cf4_t)(const void*)((const char PCP_GLOBAL*)T.ua + ((size_t)(unsigned)__builtin_amdgcn_readfirstlane(pos) << 4));
+                    v1[k] = m[-1];
+                    v2[k] = m[1];
+                } else {
+                    const gf4_t m = (gf4_t)((const char PCP_GLOBAL*)T.ua + ((unsigned)pos << 4));
+                    v1[k] = m[-1];
+                    v2[k] = m[1];
+                }
             }
         }
 #pragma unroll
