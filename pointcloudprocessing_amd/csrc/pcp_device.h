@@ -110,16 +110,18 @@ struct Target {
 // (begin+end)/2 is reduced mod L once, every later step stays inside (-L, 2L)
 // and wraps with a compare.  exclude < 0 disables the 'test != pindex' clause.
 // One level of binaryScanCircleSearch for a lane whose ring has L >= 2 points starting at beg.
-__device__ __forceinline__ void search_level(const Target& T, const float4 ref, const int beg, const int L, int& idx, int& half) {
+__device__ __forceinline__ void search_level(const Target& T, const float4 ref, const int beg, const int L, int& idx, int& half,
+                                             bool& together) {
     float c1, c2;
     if (__any(idx == 0 || idx + 1 == L)) {        // some lane of the wave is at an end of its ring
         const int i1 = (idx == 0) ? L - 1 : idx - 1;
         const int i2 = (idx + 1 == L) ? 0 : idx + 1;
         c1 = dot4(ld4i(T.ua, beg + i1), ref) + 1.0f;
         c2 = dot4(ld4i(T.ua, beg + i2), ref) + 1.0f;
-    } else if (PCP_SCALAR_LEVELS && __all(beg + idx == __builtin_amdgcn_readfirstlane(beg + idx))) {
+    } else if (together && (together = __all(beg + idx == __builtin_amdgcn_readfirstlane(beg + idx)))) {
         // every lane of the wave stands at the same place of the same ring (the first levels of neighbouring queries on
-        // one ring): the two neighbours are read once, through the scalar cache, instead of by a 64-lane gather
+        // one ring): the two neighbours are read once, through the scalar cache, instead of by a 64-lane gather.  Lanes
+        // that have parted do not meet again: `together` (the same in all lanes) ends the asking.
         typedef const pcp_f4 __attribute__((address_space(4)))* cf4_t;
         const cf4_t m = (cf4_t)(const void*)((const char PCP_GLOBAL*)T.ua + ((size_t)(unsigned)__builtin_amdgcn_readfirstlane(beg + idx) << 4));
         const pcp_f4 v1 = m[-1], v2 = m[1];
@@ -237,7 +239,8 @@ __device__ __forceinline__ void ring_window(const Target& T, const float4 q, con
     int idx = ((beg + end) / 2) % L;
     int half = L / 2;
     const int runs = 32 - __clz(L - 1);           // exact ceil(log2(L)), L >= 2
-    for (int i = 0; i < runs; ++i) search_level(T, ref, beg, L, idx, half);
+    bool together = PCP_SCALAR_LEVELS != 0;
+    for (int i = 0; i < runs; ++i) search_level(T, ref, beg, L, idx, half, together);
     window_min<CHECK, EXCL>(T, q, beg, L, idx, exclude, best, mind);
 }
 
@@ -264,6 +267,9 @@ __device__ __forceinline__ void ring_windows(const Target& T, const float4 q, co
         most = max(most, runs[k]);
     }
     for (int m = 1; m < 64; m <<= 1) most = max(most, __shfl_xor(most, m, 64));      // wave-uniform trip count
+    bool together[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) together[k] = PCP_SCALAR_LEVELS != 0;
     for (int i = 0; i < most; ++i) {
         bool edge = false;
 #pragma unroll
@@ -281,7 +287,7 @@ __device__ __forceinline__ void ring_windows(const Target& T, const float4 q, co
 #pragma unroll
             for (int k = 0; k < N; ++k) {
                 const int pos = se[k].x + idx[k];
-                if (PCP_SCALAR_LEVELS && __all(pos == __builtin_amdgcn_readfirstlane(pos))) {    // as in search_level
+                if (together[k] && (together[k] = __all(pos == __builtin_amdgcn_readfirstlane(pos)))) {    // as in search_level
                     typedef const pcp_f4 __attribute__((address_space(4)))* cf4_t;
                     const cf4_t m = (cf4_t)(const void*)((const char PCP_GLOBAL*)T.ua + ((size_t)(unsigned)__builtin_amdgcn_readfirstlane(pos) << 4));
                     v1[k] = m[-1];

@@ -19,7 +19,8 @@ def fractions(kernel):
             "waves_waiting": sq["SQ_WAIT_ANY"] / sq["SQ_WAVE_CYCLES"],
             "l2_hit_rate": l2["TCC_HIT_sum"] / (l2["TCC_HIT_sum"] + l2["TCC_MISS_sum"]),
             "valu_instructions_per_wave": sq["SQ_INSTS_VALU"] / sq["SQ_WAVES"],
-            "vmem_read_instructions_per_wave": sq["SQ_INSTS_VMEM_RD"] / sq["SQ_WAVES"]}
+            "vmem_read_instructions_per_wave": sq["SQ_INSTS_VMEM_RD"] / sq["SQ_WAVES"],
+            "scalar_memory_instructions_per_wave": (sq["SQ_INSTS_SMEM"] / sq["SQ_WAVES"]) if "SQ_INSTS_SMEM" in sq else None}
 
 
 tag = sys.argv[5] if len(sys.argv) > 5 else "r02"

@@ -19,7 +19,7 @@ timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE -d $O/fetch -o f -- $B > $O/f.log
 timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE -d $O/write -o w -- $B > $O/w.log 2>&1
 timeout -s KILL 100 rocprofv3 --pmc FETCH_SIZE -d $O/cf -o f -- $R/tools/_build/calib_traffic > $O/cf.log 2>&1
 timeout -s KILL 100 rocprofv3 --pmc WRITE_SIZE -d $O/cw -o w -- $R/tools/_build/calib_traffic > $O/cw.log 2>&1
-timeout -s KILL 200 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_ACTIVE_INST_ANY SQ_WAVES SQ_INSTS_VMEM_RD GRBM_GUI_ACTIVE -d $O/sq -o p -- $B > $O/sq.log 2>&1
+timeout -s KILL 200 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_ACTIVE_INST_ANY SQ_WAVES SQ_INSTS_VMEM_RD SQ_INSTS_SMEM GRBM_GUI_ACTIVE -d $O/sq -o p -- $B > $O/sq.log 2>&1
 timeout -s KILL 200 rocprofv3 --pmc TA_BUSY_avr TA_BUSY_max TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum GRBM_GUI_ACTIVE -d $O/ta -o p -- $B > $O/ta.log 2>&1
 timeout -s KILL 200 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum -d $O/l2 -o p -- $B > $O/l2.log 2>&1
 cd $R
