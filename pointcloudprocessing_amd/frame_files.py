@@ -120,6 +120,8 @@ class MemoryRuns:
 
     def __iter__(self):
         n = len(self.frames)
+        if n == 0:
+            return
         last = n if self.stride == self.run else max(1, n - (self.run - self.stride))
         for lo in range(0, last, self.stride):
             yield lo, [self.frames[k] for k in range(lo, min(n, lo + self.run))], None
