@@ -98,7 +98,12 @@ class FrameFileRuns:
     def close(self):
         self._stop = True
         self._free.put(None)
-        self._thread.join(timeout=10)
+        while self._thread.is_alive():                # a reader waiting to hand over a run nobody will take
+            try:
+                self._ready.get(timeout=0.05)
+            except queue.Empty:
+                pass
+        self._thread.join()
         for row in self._bufs:
             for p, _ in row:
                 self._lib.pcp_host_free(p)

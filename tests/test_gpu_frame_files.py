@@ -44,6 +44,13 @@ def test_runs_hold_the_files_in_name_order_and_recycle_their_buffers(drive):
         assert seen == [(0, 5), (4, 5), (8, 5), (12, 2)]
     finally:
         runs.close()
+    import time
+    runs = FrameFileRuns(paths, run=3, slots=2)                # a consumer that gives up after the first run
+    first = next(iter(runs))
+    assert first[0] == 0 and len(first[1]) == 3
+    c0 = time.perf_counter()
+    runs.close()                                               # the reader is waiting to hand over runs nobody takes
+    assert time.perf_counter() - c0 < 5.0
     bad = os.path.join(root, "broken.bin")
     with open(bad, "wb") as f:
         f.write(b"\0" * 20)                                    # not a whole number of rows
