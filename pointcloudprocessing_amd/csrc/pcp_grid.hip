@@ -438,7 +438,10 @@ struct Nn32Args {
     int* nn_pos;
 };
 
-__global__ void __launch_bounds__(256) k_grid_nn32(const Nn32Args A) {
+#ifndef PCP_GRID_NN_WAVES
+#define PCP_GRID_NN_WAVES 6
+#endif
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PCP_GRID_NN_WAVES, PCP_GRID_NN_WAVES))) k_grid_nn32(const Nn32Args A) {
     const GridView& G = A.G;
     __shared__ uint2 s_seg[8][32];          // per half-wave: (first point, offset in the dealt list) of 32 cells
     if (A.st && A.st->done) return;

@@ -454,8 +454,11 @@ __device__ __forceinline__ void ls_quad_body(const LsArgs& A, char* smem, const 
     if (qi < PCP_PSTRIDE) A.partials[(size_t)block * PCP_PSTRIDE + qi] = mine;
 }
 
+#ifndef PCP_LS_QUAD_WAVES
+#define PCP_LS_QUAD_WAVES 8
+#endif
 template <int MODE, bool F64SRC>
-__global__ void __launch_bounds__(256) k_ls_quad(const LsArgs A) {
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PCP_LS_QUAD_WAVES, PCP_LS_QUAD_WAVES))) k_ls_quad(const LsArgs A) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     ls_quad_body<MODE, F64SRC>(A, smem, blockIdx.x);
 }
@@ -464,7 +467,8 @@ __global__ void __launch_bounds__(256) k_ls_quad(const LsArgs A) {
 // earlier kernels of the same stream, so that the host never learns them.  Launched for a capacity; blocks
 // beyond the source's size leave at once.
 template <int MODE>
-__global__ void __launch_bounds__(256) k_ls_quad_ind(const LsArgs* __restrict__ desc) {
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PCP_LS_QUAD_WAVES, PCP_LS_QUAD_WAVES)))
+k_ls_quad_ind(const LsArgs* __restrict__ desc) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const LsArgs A = *desc;
     if ((int)(blockIdx.x * 64) >= A.n_b) return;
@@ -496,14 +500,19 @@ __device__ __forceinline__ void first_rings_body(const LsArgs& A, char* smem, co
     if (live && sub == 0 && ring >= 0) A.hint[i] = (float)ring;
 }
 
+#ifndef PCP_FIRST_RINGS_WAVES
+#define PCP_FIRST_RINGS_WAVES 8
+#endif
 template <int K, bool F64SRC>
-__global__ void __launch_bounds__(PCP_BLOCK) k_first_rings(const LsArgs A) {
+__global__ void __launch_bounds__(PCP_BLOCK) __attribute__((amdgpu_waves_per_eu(PCP_FIRST_RINGS_WAVES, PCP_FIRST_RINGS_WAVES)))
+k_first_rings(const LsArgs A) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     first_rings_body<K, F64SRC>(A, smem, blockIdx.x);
 }
 
 template <int K>
-__global__ void __launch_bounds__(PCP_BLOCK) k_first_rings_ind(const LsArgs* __restrict__ desc) {
+__global__ void __launch_bounds__(PCP_BLOCK) __attribute__((amdgpu_waves_per_eu(PCP_FIRST_RINGS_WAVES, PCP_FIRST_RINGS_WAVES)))
+k_first_rings_ind(const LsArgs* __restrict__ desc) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const LsArgs A = *desc;
     if ((int)((blockIdx.x * PCP_BLOCK) / K) >= A.n_b || A.st->done) return;
