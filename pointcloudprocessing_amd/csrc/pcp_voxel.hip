@@ -121,6 +121,23 @@ __device__ int find_voxel(const int4* __restrict__ table, const int stored, cons
     return bin_search(table, 2, z, true, fy, ly);
 }
 
+// findVoxelId on a table that IS in lexicographic order (the invariant Voxelizer.storeUnknownPoints keeps, Voxelizer.py:170-306,
+// and the device merge with it): the first entry not below (x, y, z) in one bisection.  On such a table the five bisections
+// of find_voxel end at this very entry -- the x range, the y range inside it, the first z inside that -- so the answer is the
+// same, after a fifth of the dependent loads.  Used where the library itself maintains the table (the frame feed).
+__device__ int find_voxel_sorted(const int4* __restrict__ table, const int stored, const int x, const int y, const int z) {
+    int l = 0, h = stored;
+    while (l < h) {
+        const int mid = (l + h) >> 1;
+        const int4 v = table[mid];
+        const bool below = v.x < x || (v.x == x && (v.y < y || (v.y == y && v.z < z)));
+        if (below) l = mid + 1; else h = mid;
+    }
+    if (l >= stored) return -1;
+    const int4 v = table[l];
+    return (v.x == x && v.y == y && v.z == z) ? l : -1;
+}
+
 // (x, y, z) records of 12 bytes -> the (x, y, z, 0) records the kernels read (pad_points, ComputeShader.py:956-961)
 __global__ void k_pad_xyz(const float* __restrict__ xyz, int n, float4* __restrict__ out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -515,7 +532,7 @@ k_feed_voxelize(const void* __restrict__ src, int n, const int4* __restrict__ ta
         pts[i] = p;
         if (store) store[i] = p;
         c = voxel_coord(p, voxel_size);
-        const int entry = find_voxel(table, stored, c.x, c.y, c.z);
+        const int entry = find_voxel_sorted(table, stored, c.x, c.y, c.z);
         if (entry == -1) {
             unknown = true;
         } else {
