@@ -540,9 +540,20 @@ def odometry_leg(raws, device):
         vox.init(0.5)
         cs.synchronize()
         c0 = time.perf_counter()
-        track = chain.collect(chain.submit(pinned, rows, point_to_plane=True, iterations=MAX_ITER, tol=TOL, voxelizer=vox))
+        # runs of ten frames, two in flight: the upload and decode of a run overlap the chain of the run before it
+        track, pending, dev_ms = [], [], 0.0
+        for lo in range(0, F, 10):
+            hi = min(F, lo + 10)
+            pending.append(chain.submit([pinned[k] for k in range(lo, hi)], rows[lo:hi], point_to_plane=True, iterations=MAX_ITER,
+                                        tol=TOL, voxelizer=vox))
+            if len(pending) == 2:
+                track += chain.collect(pending.pop(0))
+                dev_ms += chain.last_chain_ms
+        for t in pending:
+            track += chain.collect(t)
+            dev_ms += chain.last_chain_ms
         walls.append(time.perf_counter() - c0)
-        devs.append(chain.last_chain_ms)
+        devs.append(dev_ms)
         voxels = vox.stored_voxels
         vox.cleanup()
     chain.close()
