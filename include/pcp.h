@@ -301,6 +301,23 @@ int pcp_voxel_staged_read(pcp_ctx* ctx, int rows, int max_points, int32_t* stage
 /* Points [first, first + n) of the device point store (pcp_voxel_store_enable) as float32 rows of 4: what
  * Voxelizer.added_points holds for them (Voxelizer.py:398-425).  Waits. */
 int pcp_voxel_store_read(pcp_ctx* ctx, long long first, int n, float* xyzw);
+/* The hand-off of staged voxels (Voxelizer.addPoints :130-133: the points of every row the frame's stager released go to
+ * the voxel manager) for frames that are fed without a wait in between: while a log is open, every frame of
+ * pcp_voxel_add / _add_dev appends the points of the rows it staged -- looked up in the device point store as
+ * pcp_voxel_staged_points does, row after row in staging order, n x 3 float64 -- to the log, in stream order, so a
+ * producer that keeps many frames in flight (pcp_chain_submit) loses none of them.  Two logs (slot 0 and 1) let one run
+ * of frames be taken while the next is written:
+ *   _begin  empties the slot's log and opens it (capacity_points: the least room it must have; a slot's buffer only
+ *           grows); the context's stream first waits for `after_stream` (or NULL), the stream that read the slot's
+ *           previous contents;
+ *   _end    closes it: frames fed afterwards are not logged; the counts start their way to the host;
+ *   _take   waits for the frames fed while it was open and returns the log (device memory of the context, valid until
+ *           the slot's next _begin), its points and the rows (voxels) they came from.  A log that overflowed fails here:
+ *           the frame that did not fit left the log unchanged, its staged points are lost.
+ * One log is open at a time; the step-by-step stager calls do not write to it.  Needs pcp_voxel_store_enable. */
+int pcp_voxel_log_begin(pcp_ctx* ctx, int slot, size_t capacity_points, void* after_stream);
+int pcp_voxel_log_end(pcp_ctx* ctx, int slot);
+int pcp_voxel_log_take(pcp_ctx* ctx, int slot, const double** xyz_dev, size_t* n_points, int* n_rows);
 
 /* ---- batches of independent frame pairs -----------------------------------
  * Consecutive frame pairs of a sequence are independent registrations

@@ -74,6 +74,9 @@ SIGNATURES = {
     "pcp_voxel_stat_read": (C.c_int, [_ctx, C.c_int, _f32p]),
     "pcp_voxel_store_enable": (C.c_int, [_ctx, C.c_int]),
     "pcp_voxel_staged_points": (C.c_int, [_ctx, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), _i32p]),
+    "pcp_voxel_log_begin": (C.c_int, [_ctx, C.c_int, C.c_size_t, C.c_void_p]),
+    "pcp_voxel_log_end": (C.c_int, [_ctx, C.c_int]),
+    "pcp_voxel_log_take": (C.c_int, [_ctx, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), _i32p]),
     "pcp_grid_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
     "pcp_grid_destroy": (C.c_int, [C.c_void_p]),
     "pcp_grid_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),

@@ -112,6 +112,10 @@ class CellGrid:
                 check(self._lib.pcp_grid_collect_end(self._g))
         return _collect()
 
+    def synchronize(self):
+        """Returns when everything enqueued on the grid's stream has completed."""
+        check(self._lib.pcp_grid_synchronize(self._g))
+
     def defer_appends(self, on=True):
         """While on, appends wait on the device and join the map, all at once, when it is next read
         (pcp_grid_defer_appends): an append costs a copy, the merge is paid once per reader."""

@@ -39,12 +39,13 @@ class OdometryChain:
     """One drive on one device.  submit() takes the next frames of the drive, collect() returns per frame
     (guess, refined position, t_opt, R_opt, steps (iters, 6) float32, converged)."""
 
-    def __init__(self, max_frames=32, max_points=131072, max_scans=100, device=0, reset_every=10):
+    def __init__(self, max_frames=32, max_points=131072, max_scans=100, device=0, reset_every=10, stage_log_points=None):
         self._lib = _lib.load()
         self._chain = C.c_void_p()
         check(self._lib.pcp_chain_create(int(device), int(max_frames), int(max_points), int(max_scans), C.byref(self._chain)))
         self.max_frames, self.max_points, self.max_scans, self.device = int(max_frames), int(max_points), int(max_scans), int(device)
         self.reset_every = int(reset_every)          # EnvironmentConstructor.reset_origin_treshold (:35)
+        self.stage_log_points = stage_log_points     # room for the points a run's frames stage (default: twice the run's points)
         self._runs = {}
 
     def reset(self):
@@ -55,7 +56,8 @@ class OdometryChain:
         """raw_frames: (N, 4) float32 C-contiguous arrays (rows of a velodyne .bin; page-locked ones, sequence.PinnedFrames,
         upload asynchronously) that must not change until collect(); imu: (F, 12) rows of imu_rows().  voxelizer: a
         Voxelizer of this package whose map lives on the device (init() called): every frame's final cloud is fed to it as
-        Voxelizer.addPoints would (EnvironmentConstructor.py:189, :245).  Returns a ticket."""
+        Voxelizer.addPoints would (EnvironmentConstructor.py:189, :245); when its voxel manager is a map_sink.MapSink
+        working on the device, the points of every voxel the run's frames stage reach it at collect().  Returns a ticket."""
         frames = [raw_frames[k] for k in range(len(raw_frames))]
         for a in frames:
             if not (isinstance(a, np.ndarray) and a.dtype == np.float32 and a.ndim == 2 and a.shape[1] == 4 and a.flags.c_contiguous):
@@ -68,22 +70,32 @@ class OdometryChain:
         R = np.ascontiguousarray(lidar.aligning_rotation() if rotation is None else rotation, dtype=np.float64)
         ticket, serial0 = C.c_int(-1), C.c_int(-1)
         kept = np.zeros(len(frames), dtype=np.int32)
-        vctx, size, stored, begin, width, filt = None, 0.0, 0, 0, 1024, 0
+        vctx, size, stored, begin, width, filt, log_slot = None, 0.0, 0, 0, 1024, 0, None
         if voxelizer is not None:
             vctx, size, stored, begin, width, filt = voxelizer._feed_begin()
-        check(self._lib.pcp_chain_submit(self._chain, ptrs, i32p(sizes), len(frames), float(min_range), f64p(R), f64p(imu),
-                                         MODE_PLANE if point_to_plane else MODE_POINT, int(iterations), float(tol),
-                                         int(closing_iterations), self.reset_every, vctx, float(size), int(stored), int(begin),
-                                         int(width), int(filt), 1024, C.byref(ticket), i32p(kept), C.byref(serial0)))
+            room = self.stage_log_points or max(1 << 20, 2 * len(frames) * self.max_points)
+            log_begin = getattr(voxelizer, "_log_begin", None)      # a feed without a hand-off of staged voxels has none
+            log_slot = log_begin(room) if log_begin else None
+        try:
+            check(self._lib.pcp_chain_submit(self._chain, ptrs, i32p(sizes), len(frames), float(min_range), f64p(R), f64p(imu),
+                                             MODE_PLANE if point_to_plane else MODE_POINT, int(iterations), float(tol),
+                                             int(closing_iterations), self.reset_every, vctx, float(size), int(stored), int(begin),
+                                             int(width), int(filt), 1024, C.byref(ticket), i32p(kept), C.byref(serial0)))
+        except Exception:
+            if log_slot is not None:
+                voxelizer._log_end(log_slot, drop=True)
+            raise
+        if log_slot is not None:
+            voxelizer._log_end(log_slot)
         if voxelizer is not None:
             voxelizer._feed_noted(kept, serial0.value)
-        self._runs[ticket.value] = (frames, len(frames), int(max(iterations, closing_iterations)), voxelizer, kept)
+        self._runs[ticket.value] = (frames, len(frames), int(max(iterations, closing_iterations)), voxelizer, kept, log_slot)
         return ticket.value
 
     def collect(self, ticket):
         """-> list per frame of (guess (3,), position (3,), t_opt (3,), R_opt (3, 3), steps (iters, 6) float32, converged);
         self.last_chain_ms = device time of the run's chain."""
-        frames, F, cap, voxelizer, kept = self._runs.pop(ticket)
+        frames, F, cap, voxelizer, kept, log_slot = self._runs.pop(ticket)
         guess, pos, t_opt, R_opt = np.zeros((F, 3)), np.zeros((F, 3)), np.zeros((F, 3)), np.zeros((F, 3, 3))
         dx = np.zeros((F, cap, 6), dtype=np.float32)
         iters, conv = np.zeros(F, dtype=np.int32), np.zeros(F, dtype=np.int32)
@@ -93,7 +105,7 @@ class OdometryChain:
                                               cap, i32p(iters), i32p(conv), C.byref(ms)))
         finally:
             if voxelizer is not None:
-                voxelizer._feed_wait()
+                voxelizer._feed_wait(log_slot)
         self.last_chain_ms = float(ms.value)
         self.last_points = kept
         return [(guess[f], pos[f], t_opt[f], R_opt[f], dx[f, :iters[f]].copy(), bool(conv[f])) for f in range(F)]

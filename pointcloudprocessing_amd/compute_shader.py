@@ -537,6 +537,21 @@ class ComputeShader:
         check(self._lib.pcp_voxel_staged_points(self._ctx, C.byref(ptr), C.byref(n), i32p(rows)))
         return (ptr.value or 0), int(n.value), int(rows[0])
 
+    def stagedLogBegin(self, slot, capacity_points, after_stream=None):
+        """Opens log `slot` (0 or 1): every frame fed from now on (voxelAddFrame, a chain's feed) appends the points of the
+        rows it staged (pcp_voxel_log_begin).  after_stream: HIP stream that read the slot's previous contents."""
+        check(self._lib.pcp_voxel_log_begin(self._ctx, int(slot), int(capacity_points), C.c_void_p(after_stream or 0)))
+
+    def stagedLogEnd(self, slot):
+        check(self._lib.pcp_voxel_log_end(self._ctx, int(slot)))
+
+    def stagedLogTake(self, slot):
+        """Waits for the frames fed while the log was open -> (device address of n x 3 float64, n, rows staged); valid
+        until the slot is opened again."""
+        ptr, n, rows = C.c_void_p(), C.c_size_t(0), np.zeros(1, dtype=np.int32)
+        check(self._lib.pcp_voxel_log_take(self._ctx, int(slot), C.byref(ptr), C.byref(n), i32p(rows)))
+        return (ptr.value or 0), int(n.value), int(rows[0])
+
     def getFullVoxelData(self, prev_stored_voxels, max_points, voxelizer_voxel_data):
         """:946-954 -- fills voxelizer_voxel_data[:prev_stored_voxels] in place."""
         out = voxelizer_voxel_data

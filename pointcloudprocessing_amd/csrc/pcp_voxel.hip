@@ -61,6 +61,14 @@ struct pcp_voxel_state {
     unsigned* staged_off = nullptr;          // staged_off_rows + 2: exclusive scan of the staged rows' point counts, total, error flag
     int staged_off_rows = 0;
     double* staged_xyz = nullptr; size_t staged_cap = 0;
+    // ---- log of staged points (pcp_voxel_log_*): every fed frame appends the points of the rows it staged to the open slot
+    double* log_xyz[2] = {nullptr, nullptr}; size_t log_cap[2] = {0, 0};      // capacity in points
+    unsigned* log_ctl = nullptr;             // device, 4 words per slot: points, overflow flag, bad-id flag, rows
+    unsigned* log_host = nullptr;            // page-locked copy, written by pcp_voxel_log_end
+    unsigned* log_off = nullptr; int log_off_rows = 0;    // per staged row: where its points start in the log; [rows + 1] = rows to copy
+    hipEvent_t log_done[2] = {nullptr, nullptr};
+    int log_state[2] = {0, 0};               // 0 idle, 1 open (frames append), 2 closed (count on its way), per slot
+    int log_slot = -1;                       // the open slot
 };
 
 // Control block of the frame feed (pcp_voxel_add*), in device memory.
@@ -77,10 +85,13 @@ void pcp_voxel_state_free(pcp_voxel_state* v) {
     if (!v) return;
     void* bufs[] = {v->table, v->data, v->stat, v->stat_in, v->stage, v->unknown, v->pts, v->debug, v->counter,
                     v->table2, v->flag, v->k0, v->k1, v->v0, v->v1, v->heads, v->hist, v->totals, v->base, v->counts, v->mm,
-                    v->store, v->staged_off, v->staged_xyz, v->feed, v->feed_rec_dev, v->tile_counts, v->rs_base, v->feed_in};
+                    v->store, v->staged_off, v->staged_xyz, v->feed, v->feed_rec_dev, v->tile_counts, v->rs_base, v->feed_in,
+                    v->log_xyz[0], v->log_xyz[1], v->log_ctl, v->log_off};
     for (void* p : bufs)
         if (p) (void)hipFree(p);
     if (v->feed_rec) (void)hipHostFree(v->feed_rec);
+    if (v->log_host) (void)hipHostFree(v->log_host);
+    for (hipEvent_t ev : v->log_done) if (ev) (void)hipEventDestroy(ev);
     for (hipEvent_t ev : v->feed_done) if (ev) (void)hipEventDestroy(ev);
     if (v->feed_after) (void)hipEventDestroy(v->feed_after);
     delete v;
@@ -458,6 +469,65 @@ __global__ void __launch_bounds__(256) k_staged_gather(const int* __restrict__ s
         double x = 0.0, y = 0.0, z = 0.0;
         if (id < 0 || (size_t)id >= store_n) {
             off[rows + 1] = 1;                                     // an id the store does not hold
+        } else {
+            const float4 p = store[id];
+            x = (double)p.x; y = (double)p.y; z = (double)p.z;
+        }
+        double* o = out + 3 * (size_t)(first + j);
+        o[0] = x; o[1] = y; o[2] = z;
+    }
+}
+
+// The same for the rows a fed frame staged, appended to a log other frames have written to before: the number of rows is
+// the device's (counter[0] of the stager that just ran), the points go behind the ctl[0] points the log holds.  A frame whose
+// points do not fit leaves the log as it was and raises ctl[1].  off[max_rows + 1] = rows k_log_gather copies.
+__global__ void __launch_bounds__(1024) k_log_offsets(const int* __restrict__ stage, const int* __restrict__ counter, int max_rows,
+                                                       int width, unsigned* __restrict__ off, unsigned* __restrict__ ctl,
+                                                       unsigned capacity) {
+    __shared__ unsigned sc[1024];
+    __shared__ unsigned run;
+    const int rows = max(0, min(counter[0], max_rows));
+    const unsigned base = ctl[0];
+    if (threadIdx.x == 0) run = 0;
+    __syncthreads();
+    for (int first = 0; first < rows; first += 1024) {
+        const int r = first + threadIdx.x;
+        unsigned n = 0;
+        if (r < rows) n = (unsigned)max(0, min(stage[(size_t)r * width], width - 1));
+        sc[threadIdx.x] = n;
+        __syncthreads();
+        for (int d = 1; d < 1024; d <<= 1) {
+            const unsigned t = threadIdx.x >= (unsigned)d ? sc[threadIdx.x - d] : 0u;
+            __syncthreads();
+            sc[threadIdx.x] += t;
+            __syncthreads();
+        }
+        if (r < rows) off[r] = base + run + sc[threadIdx.x] - n;
+        __syncthreads();
+        if (threadIdx.x == 0) run += sc[1023];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const bool fits = (unsigned long long)base + run <= capacity;
+        off[rows] = base + run;
+        off[max_rows + 1] = fits ? (unsigned)rows : 0u;
+        if (fits) { ctl[0] = base + run; ctl[3] += (unsigned)rows; }
+        else ctl[1] = 1;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_log_gather(const int* __restrict__ stage, int width, const float4* __restrict__ store,
+                                                     size_t store_n, const unsigned* __restrict__ off, int max_rows,
+                                                     double* __restrict__ out, unsigned* __restrict__ ctl) {
+    const int r = blockIdx.x;
+    if ((unsigned)r >= off[max_rows + 1]) return;
+    const unsigned first = off[r], n = off[r + 1] - first;
+    const int* ids = stage + (size_t)r * width + 1;
+    for (unsigned j = threadIdx.x; j < n; j += blockDim.x) {
+        const int id = ids[j];
+        double x = 0.0, y = 0.0, z = 0.0;
+        if (id < 0 || (size_t)id >= store_n) {
+            ctl[2] = 1;                                            // an id the store does not hold
         } else {
             const float4 p = store[id];
             x = (double)p.x; y = (double)p.y; z = (double)p.z;
@@ -1432,6 +1502,21 @@ int feed_enqueue(pcp_ctx* c, const void* pts_dev, int layout, int n, float voxel
     const int stage_blocks = cdiv((int)std::max(ub, 1ll), 256);
     hipLaunchKernelGGL(k_voxel_stage, dim3(stage_blocks), dim3(256), 0, s, v->table, 0, v->data, v->data_rows, max_points, v->stat,
                        v->stat_in, v->stat_rows, v->stage, max_staging, 0, filter_outliers ? 0 : 1, v->counter, (const VoxFeed*)v->feed);
+    if (v->log_slot >= 0) {                             // the staged rows' points join the open log (this frame's are in the store)
+        const int k = v->log_slot;
+        if (max_staging > v->log_off_rows) {
+            PCP_CHECK(hipStreamSynchronize(s));
+            if (v->log_off) PCP_CHECK(hipFree(v->log_off));
+            v->log_off = nullptr; v->log_off_rows = 0;
+            PCP_CHECK(hipMalloc(&v->log_off, ((size_t)max_staging + 2) * sizeof(unsigned)));
+            v->log_off_rows = max_staging;
+        }
+        hipLaunchKernelGGL(k_log_offsets, dim3(1), dim3(1024), 0, s, v->stage, v->counter, max_staging, max_points, v->log_off,
+                           v->log_ctl + 4 * k, (unsigned)std::min<size_t>(v->log_cap[k], 0xffffffffu));
+        hipLaunchKernelGGL(k_log_gather, dim3(max_staging), dim3(256), 0, s, v->stage, max_points, v->store, v->store_n, v->log_off,
+                           max_staging, v->log_xyz[k], v->log_ctl + 4 * k);
+        PCP_CHECK(hipGetLastError());
+    }
     // the new voxels
     hipLaunchKernelGGL(k_feed_emit, grid, block, 0, s, v->pts, v->flag, n, v->tile_counts, tiles, v->feed, begin_index, voxel_size,
                        v->k0, v->v0);
@@ -1572,6 +1657,68 @@ int pcp_voxel_store_read(pcp_ctx* c, long long first, int n, float* xyzw) {
     if ((size_t)first + (size_t)n > v->store_n) return pcp_fail("points [%lld, %lld) requested, %zu stored", first, first + n, v->store_n);
     PCP_CHECK(hipMemcpyAsync(xyzw, v->store + first, (size_t)n * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
     PCP_CHECK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int pcp_voxel_log_begin(pcp_ctx* c, int slot, size_t capacity_points, void* after_stream) {
+    if (int e = use(c, false)) return e;
+    pcp_voxel_state* v = c->vox;
+    if (slot < 0 || slot > 1) return pcp_fail("slot %d: there are two logs, 0 and 1", slot);
+    if (capacity_points < 1 || capacity_points > 0xffffffffu) return pcp_fail("capacity of %zu points outside [1, 2^32)", capacity_points);
+    if (!v->keep_store) return pcp_fail("the log resolves staged rows through the device point store (pcp_voxel_store_enable)");
+    if (v->log_slot >= 0) return pcp_fail("log %d is open: pcp_voxel_log_end first", v->log_slot);
+    if (v->log_state[slot] == 2) return pcp_fail("log %d has not been taken (pcp_voxel_log_take)", slot);
+    hipStream_t s = c->stream;
+    if (!v->log_ctl) {
+        PCP_CHECK(hipMalloc(&v->log_ctl, 8 * sizeof(unsigned)));
+        PCP_CHECK(hipHostMalloc((void**)&v->log_host, 8 * sizeof(unsigned)));
+        for (int k = 0; k < 2; ++k) PCP_CHECK(hipEventCreateWithFlags(&v->log_done[k], hipEventDisableTiming));
+    }
+    if (capacity_points > v->log_cap[slot]) {           // the slot is idle: nothing reads its old buffer on this stream
+        PCP_CHECK(hipStreamSynchronize(s));
+        if (v->log_xyz[slot]) PCP_CHECK(hipFree(v->log_xyz[slot]));
+        v->log_xyz[slot] = nullptr; v->log_cap[slot] = 0;
+        PCP_CHECK(hipMalloc(&v->log_xyz[slot], capacity_points * 3 * sizeof(double)));
+        v->log_cap[slot] = capacity_points;
+    }
+    if (after_stream && (hipStream_t)after_stream != s) {          // whoever read the slot's last contents
+        if (!v->feed_after) PCP_CHECK(hipEventCreateWithFlags(&v->feed_after, hipEventDisableTiming));
+        PCP_CHECK(hipEventRecord(v->feed_after, (hipStream_t)after_stream));
+        PCP_CHECK(hipStreamWaitEvent(s, v->feed_after, 0));
+    }
+    PCP_CHECK(hipMemsetAsync(v->log_ctl + 4 * slot, 0, 4 * sizeof(unsigned), s));
+    v->log_state[slot] = 1;
+    v->log_slot = slot;
+    return 0;
+}
+
+int pcp_voxel_log_end(pcp_ctx* c, int slot) {
+    if (int e = use(c, false)) return e;
+    pcp_voxel_state* v = c->vox;
+    if (slot < 0 || slot > 1 || v->log_slot != slot) return pcp_fail("log %d is not open", slot);
+    PCP_CHECK(hipMemcpyAsync(v->log_host + 4 * slot, v->log_ctl + 4 * slot, 4 * sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+    PCP_CHECK(hipEventRecord(v->log_done[slot], c->stream));
+    v->log_state[slot] = 2;
+    v->log_slot = -1;
+    return 0;
+}
+
+int pcp_voxel_log_take(pcp_ctx* c, int slot, const double** xyz_dev, size_t* n_points, int* n_rows) {
+    if (int e = use(c, false)) return e;
+    pcp_voxel_state* v = c->vox;
+    if (!xyz_dev || !n_points) return pcp_fail("null output");
+    *xyz_dev = nullptr; *n_points = 0;
+    if (n_rows) *n_rows = 0;
+    if (slot < 0 || slot > 1 || v->log_state[slot] != 2) return pcp_fail("log %d has not been ended (pcp_voxel_log_end)", slot);
+    PCP_CHECK(hipEventSynchronize(v->log_done[slot]));
+    v->log_state[slot] = 0;
+    const unsigned* h = v->log_host + 4 * slot;
+    if (h[1]) return pcp_fail("the log of %zu points overflowed after %u points: the staged points of at least one frame are lost "
+                              "(open it with a larger capacity)", v->log_cap[slot], h[0]);
+    if (h[2]) return pcp_fail("a staged row names a point the device store does not hold (%zu points stored)", v->store_n);
+    *xyz_dev = v->log_xyz[slot];
+    *n_points = h[0];
+    if (n_rows) *n_rows = (int)h[3];
     return 0;
 }
 

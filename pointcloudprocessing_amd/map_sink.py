@@ -42,6 +42,24 @@ class MapSink:
         self.voxels_fed += rows
         return n
 
+    def stagedLogTaken(self, ptr, n, rows):
+        """A run of frames fed without waits in between (chain.OdometryChain) hands over what all of them staged: n points
+        of `rows` voxels in device memory (ComputeShader.stagedLogTake)."""
+        if n:
+            if hasattr(self.target, "ingest_device"):
+                self.target.ingest_device(ptr, n)
+            else:
+                self.target.append_device(ptr, n)
+        self.points_fed += n
+        self.voxels_fed += rows
+        return n
+
+    def beforeLogReuse(self):
+        """The copies out of a log handed over earlier have completed when this returns."""
+        grid = self._grid()
+        if grid is not None and hasattr(grid, "synchronize"):
+            grid.synchronize()
+
     def _grid(self):
         if hasattr(self.target, "collect"):
             return self.target

@@ -194,7 +194,7 @@ class Voxelizer:
         return (self.feed_frames and self.inited and hasattr(c, "voxelAddFrame") and getattr(c, "_voxel_resident", None) == self.stored_voxels
                 and bool(getattr(c, "resident_statistics", False)) and getattr(c, "voxel_map_epoch", None) == self._map_epoch)
 
-    def _took_frame(self, rec):
+    def _took_frame(self, rec, hand_off=True):
         """Book-keeping after a fed frame: sizes follow the reference's growth rule, contents are fetched on demand."""
         prev = self.stored_voxels
         self._index_stale = self._rows_stale = self._stats_stale = True      # the device holds the contents
@@ -202,7 +202,8 @@ class Voxelizer:
         while rec.stored >= len(self._voxel_index):
             self._grow()
         self.realloc_needed, self.prev_stored_voxels, self.last_run_realloc = False, prev, False
-        self._hand_off(_StagedRows(self.compute, rec.staged, self.max_points))
+        if hand_off:
+            self._hand_off(_StagedRows(self.compute, rec.staged, self.max_points))
 
     def addPoints(self, np_points, colors, printt=False):
         if self._can_feed():
@@ -264,12 +265,42 @@ class Voxelizer:
         self.compute._feed_clean = True
         self.__dict__.setdefault("_feed_tickets", []).append(int(first_serial) + len(counts) - 1)
 
-    def _feed_wait(self):
-        """Waits for the oldest run of enqueued frames and takes its last record (voxels stored, rows staged by the last
-        frame; the staged rows of the frames before it are not kept)."""
+    def _log_begin(self, capacity_points):
+        """Before a producer enqueues a run of frames: when the voxel manager takes staged points on the device (a
+        map_sink.MapSink made with this map's ComputeShader), the run's frames log the points of the rows they stage
+        (ComputeShader.stagedLogBegin) -> the log's slot, else None (only the last frame's rows are handed on then)."""
+        sink = self.voxman
+        if sink is None or getattr(sink, "compute", None) is not self.compute or not hasattr(sink, "stagedLogTaken"):
+            return None
+        slot = self.__dict__.get("_log_next", 0)
+        sink.beforeLogReuse()                          # whatever the sink still copies out of this slot's last contents
+        self.compute.stagedLogBegin(slot, int(capacity_points))
+        self._log_next = 1 - slot
+        return slot
+
+    def _log_end(self, slot, drop=False):
+        self.compute.stagedLogEnd(slot)
+        if drop:                                       # the run was never enqueued whole: nothing of it is handed on
+            try:
+                self.compute.stagedLogTake(slot)
+            except RuntimeError:
+                pass
+
+    def _feed_wait(self, log_slot=None):
+        """Waits for the oldest run of enqueued frames and takes its last record (voxels stored).  With a log
+        (_log_begin) the points every frame of the run staged go to the voxel manager; without one only the rows staged by
+        the last frame are handed on (the staged rows of the frames before it are not kept)."""
         tickets = self.__dict__.get("_feed_tickets") or []
-        if tickets:
+        if not tickets:
+            return
+        if log_slot is None:
             self._took_frame(self.compute.voxelAddWait(tickets.pop(0)))
+            return
+        try:
+            self._took_frame(self.compute.voxelAddWait(tickets.pop(0)), hand_off=False)
+        finally:
+            ptr, n, rows = self.compute.stagedLogTake(log_slot)
+        self.voxman.stagedLogTaken(ptr, n, rows)
 
     def _stage(self, everything):
         """One stager dispatch (:116-119, :141-152) -> the staged rows.  With the statistics resident on the device the

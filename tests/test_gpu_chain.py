@@ -19,7 +19,7 @@ def _raw4(raw3):
     return np.ascontiguousarray(np.column_stack([raw3, np.zeros(len(raw3), np.float32)]), dtype=np.float32)
 
 
-def _host_driven(n_frames, voxel=0.5):
+def _host_driven(n_frames, voxel=0.5, sink=None):
     """The frame-by-frame driver -> (prev_poses, [(placed, iterations, full_iter, (t_opt, R_opt), steps)], clouds fed to
     the voxel map, voxelizer, compute shader)."""
     ox = reader_from_golden(golden("ref_imu.npz"))
@@ -28,7 +28,7 @@ def _host_driven(n_frames, voxel=0.5):
         reader.add_frame(f"{k:010d}", _raw4(raw))
     cs = ComputeShader(maxPointsPerCloud=200000, maxScans=100)
     icp = PointcloudIcpContainer(cs)
-    vox = Voxelizer(cs, None)
+    vox = Voxelizer(cs, None, voxman=sink(cs) if sink else None)
     env = EnvironmentConstructor(None, ox, reader, icp, cs, voxelizer=vox)
     calls, fed, steps = [], [], []
     plain_refine, plain_add, plain_run = env.getRefinedTransition, vox.addPoints, cs.icpRun
@@ -128,6 +128,61 @@ def test_chain_equals_the_frame_by_frame_driver():
         env.cleanup()
         cs.cleanup()
         cs_h.cleanup()
+
+
+def test_chain_hands_every_staged_voxel_to_the_map():
+    """Voxelizer.addPoints hands the points of the voxels each frame stages to the voxel manager (Voxelizer.py:130-133).
+    The frame-by-frame driver does so after every frame; the chain keeps runs of frames in flight and delivers what all
+    of them staged when a run is collected.  Both maps receive the same voxels with the same number of points each (which
+    ids a row keeps once more points than it holds have arrived is decided by the race of the appends, in the reference as
+    here: VoxelShader.glsl:141-145), and every point the chain's map receives is a point of its store."""
+    from pointcloudprocessing_amd import CellGrid, MapSink
+    n_frames = 30
+    grids = [CellGrid(np.zeros((0, 3)), cell=1.0) for _ in range(2)]
+    sinks = []
+
+    def host_sink(cs):
+        sinks.append(MapSink(grids[0], compute=cs))
+        return sinks[0]
+
+    poses, calls, fed, vox_h, cs_h, env = _host_driven(n_frames, voxel=2.0, sink=host_sink)
+    ox = reader_from_golden(golden("ref_imu.npz"))
+    rows, _, _, _ = imu_rows([ox.getOx(k) for k in ox.getfilenames()[:n_frames]])
+    pinned = PinnedFrames([_raw4(r) for r in kitti_all_raw()[:n_frames]])
+    cs = ComputeShader(maxPointsPerCloud=200000, maxScans=100)
+    sink = MapSink(grids[1], compute=cs)
+    vox = Voxelizer(cs, None, voxman=sink)
+    vox.separate_colors, vox.filter_outliers = vox_h.separate_colors, vox_h.filter_outliers
+    vox.init(2.0)
+    chain = OdometryChain(max_frames=7, max_points=131072)
+    try:
+        tickets, got = [], []
+        for lo in range(0, n_frames, 7):                       # runs of 7, 7, 7, 7, 2 frames, two in flight
+            hi = min(n_frames, lo + 7)
+            tickets.append(chain.submit([pinned[k] for k in range(lo, hi)], rows[lo:hi], voxelizer=vox))
+            if len(tickets) == 2:
+                got += chain.collect(tickets.pop(0))
+        got += chain.collect(tickets.pop(0))
+        for k in range(n_frames):
+            assert np.array_equal(got[k][1], poses[k][1]), k
+        assert vox.stored_voxels == vox_h.stored_voxels
+        assert sinks[0].points_fed > 100000                    # the drive does stage voxels
+        assert (sink.points_fed, sink.voxels_fed) == (sinks[0].points_fed, sinks[0].voxels_fed)
+        a, b = grids[1].sorted_points()[1], grids[0].sorted_points()[1]
+        assert len(a) == sink.points_fed == len(b)
+        per_voxel = lambda x: np.unique(vox.vectorizedGetVoxelCoord(x), axis=0, return_counts=True)
+        (va, ca), (vb, cb) = per_voxel(a), per_voxel(b)
+        assert len(va) == sink.voxels_fed and np.array_equal(va, vb) and np.array_equal(ca, cb)
+        store = vox.added_points[:vox.last_added_point, :3].astype(np.float64)
+        assert len(np.unique(np.concatenate([a, store]), axis=0)) == len(np.unique(store, axis=0))
+    finally:
+        chain.close()
+        pinned.close()
+        env.cleanup()
+        cs.cleanup()
+        cs_h.cleanup()
+        for g in grids:
+            g.cleanup()
 
 
 def test_chain_reports_a_reference_it_cannot_prepare():

@@ -478,6 +478,84 @@ def test_frames_fed_from_device_memory_and_without_waiting(compute):
         other.cleanup()
 
 
+def _rows_sorted(xyz):
+    return xyz[np.lexsort((xyz[:, 2], xyz[:, 1], xyz[:, 0]))]
+
+
+def test_the_log_holds_what_every_fed_frame_staged(compute):
+    """pcp_voxel_log_*: while a log is open every fed frame appends the points of the rows it staged.  Here the frames
+    are fed one at a time, so the per-frame hand-off (pcp_voxel_staged_points after each wait, Voxelizer.py:130-133)
+    sees the same rows: the log taken at the end holds exactly the points those hand-offs put into a map, and as many
+    rows."""
+    from pointcloudprocessing_amd import CellGrid, MapSink
+    frames = _raw_frames(10)
+    per_frame, whole = CellGrid(np.zeros((0, 3)), cell=1.0), CellGrid(np.zeros((0, 3)), cell=1.0)
+    try:
+        sink = MapSink(per_frame, compute=compute)
+        v = Voxelizer(compute, None, voxman=sink)
+        v.init(2.0)
+        v.filter_outliers = False
+        with pytest.raises(PcpError, match="not been ended"):
+            compute.stagedLogTake(0)
+        compute.stagedLogBegin(0, 4 << 20)
+        with pytest.raises(PcpError, match="is open"):
+            compute.stagedLogBegin(1, 1024)
+        for f in frames[:6]:
+            v.addPoints(f, None)
+        compute.stagedLogEnd(0)
+        with pytest.raises(PcpError, match="not open"):
+            compute.stagedLogEnd(0)
+        with pytest.raises(PcpError, match="not been taken"):
+            compute.stagedLogBegin(0, 1024)
+        fed_before = sink.points_fed
+        # the other log takes the next frames while the first waits to be taken
+        compute.stagedLogBegin(1, 4 << 20)
+        for f in frames[6:]:
+            v.addPoints(f, None)
+        compute.stagedLogEnd(1)
+        ptr0, n0, rows0 = compute.stagedLogTake(0)
+        ptr1, n1, rows1 = compute.stagedLogTake(1)
+        assert n0 == fed_before > 0 and n0 + n1 == sink.points_fed and rows0 + rows1 == sink.voxels_fed
+        assert n1 > 0 and ptr0 != ptr1
+        whole.append_device(ptr0, n0)
+        whole.append_device(ptr1, n1)
+        got, want = whole.sorted_points()[1], per_frame.sorted_points()[1]
+        assert len(got) == n0 + n1 and np.array_equal(_rows_sorted(got), _rows_sorted(want))
+        # every logged point is a point of the store
+        store = compute.readPointStore(0, v.last_added_point)[:, :3].astype(np.float64)
+        assert len(np.unique(np.concatenate([_rows_sorted(got), store]), axis=0)) == len(np.unique(store, axis=0))
+    finally:
+        per_frame.cleanup()
+        whole.cleanup()
+
+
+def test_the_log_needs_the_point_store_and_room():
+    from pointcloudprocessing_amd import ComputeShader
+    cs = ComputeShader(maxPointsPerCloud=200000, maxScans=10)
+    try:
+        v = Voxelizer(cs, None)
+        v.init(2.0)
+        v.filter_outliers = False
+        with pytest.raises(PcpError, match="point store"):
+            cs.stagedLogBegin(0, 1024)
+        with pytest.raises(PcpError, match="two logs"):
+            cs.stagedLogBegin(2, 1024)
+        # a log too small for a frame's staged points says so when it is taken; the slot is usable afterwards
+        cs.keepPointStore(True)
+        v.init(2.0)
+        cs.stagedLogBegin(0, 16)
+        for f in _raw_frames(8):
+            v.addPoints(f, None)
+        cs.stagedLogEnd(0)
+        with pytest.raises(PcpError, match="overflowed"):
+            cs.stagedLogTake(0)
+        cs.stagedLogBegin(0, 16)
+        cs.stagedLogEnd(0)
+        assert cs.stagedLogTake(0)[1:] == (0, 0)
+    finally:
+        cs.cleanup()
+
+
 def test_a_frame_too_wide_for_the_keys_is_refused(compute):
     v = Voxelizer(compute, None)
     v.init(0.5)

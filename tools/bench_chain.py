@@ -8,12 +8,14 @@ import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402
-from pointcloudprocessing_amd import ComputeShader, PinnedFrames, Voxelizer  # noqa: E402
+from pointcloudprocessing_amd import CellGrid, ComputeShader, MapSink, PinnedFrames, Voxelizer  # noqa: E402
 from pointcloudprocessing_amd.chain import OdometryChain, imu_rows  # noqa: E402
 from pointcloudprocessing_amd.oxts import OxtsDataReader, parse_timestamp  # noqa: E402
 
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 6
 with_map = not (len(sys.argv) > 2 and sys.argv[2] == "nomap")
+with_sink = len(sys.argv) > 2 and sys.argv[2] == "sink"      # staged voxels go to a cell grid (2 m voxels so that rows fill up)
+voxel = 2.0 if with_sink else 0.5
 raws, _ = bench.real_frames()
 g = np.load(os.path.join(bench.GOLD, "ref_imu.npz"))
 rd = OxtsDataReader()
@@ -27,10 +29,14 @@ chain = OdometryChain(max_frames=len(raws), max_points=1 << 17)
 for rep in range(reps):
     chain.reset()
     vox = None
+    grid = sink = None
     if with_map:
-        vox = Voxelizer(cs, None)
+        if with_sink:
+            grid = CellGrid(np.zeros((0, 3)), cell=1.0)
+            sink = MapSink(grid, compute=cs)
+        vox = Voxelizer(cs, None, voxman=sink)
         vox.separate_colors, vox.filter_outliers = False, False
-        vox.init(0.5)
+        vox.init(voxel)
     cs.synchronize()
     c0 = time.perf_counter()
     ticket = chain.submit(pinned, rows, voxelizer=vox)
@@ -39,9 +45,12 @@ for rep in range(reps):
     wall = time.perf_counter() - c0
     print("rep %d: %.3f ms per frame wall (%.3f of it the enqueue), %.3f ms per frame on the chain's stream, %.1f iterations per frame%s"
           % (rep, wall / len(raws) * 1e3, enq / len(raws) * 1e3, chain.last_chain_ms / len(raws), np.mean([len(t[4]) for t in track[1:]]),
-             ", %d voxels" % vox.stored_voxels if vox else ""), flush=True)
+             (", %d voxels" % vox.stored_voxels if vox else "")
+             + (", %d points of %d staged voxels in the map" % (sink.points_fed, sink.voxels_fed) if sink else "")), flush=True)
     if vox:
         vox.cleanup()
+    if grid:
+        grid.cleanup()
 chain.close()
 pinned.close()
 cs.cleanup()
