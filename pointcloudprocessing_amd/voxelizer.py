@@ -274,7 +274,16 @@ class Voxelizer:
             return None
         slot = self.__dict__.get("_log_next", 0)
         sink.beforeLogReuse()                          # whatever the sink still copies out of this slot's last contents
-        self.compute.stagedLogBegin(slot, int(capacity_points))
+        try:
+            self.compute.stagedLogBegin(slot, int(capacity_points))
+        except RuntimeError as e:
+            if "has not been taken" not in str(e):
+                raise
+            try:                                       # the log of a run its producer abandoned (never collected)
+                self.compute.stagedLogTake(slot)
+            except RuntimeError:
+                pass
+            self.compute.stagedLogBegin(slot, int(capacity_points))
         self._log_next = 1 - slot
         return slot
 
