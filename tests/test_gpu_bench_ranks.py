@@ -29,9 +29,9 @@ def test_bench_with_two_ranks_on_one_card():
     assert len(lines) == 1, done.stdout[-2000:]              # rank 0 prints ONE line
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["steps"] == 2 and out["warmup"] == 1 and out["scaling"] == "weak"
-    assert out["value"] > 0 and out["config"]["pairs_per_gpu_per_step"] == 64
+    assert out["value"] > 0 and out["config"]["pairs_per_gpu_per_step"] == 256
     # whole-job value: both ranks' pairs over the slower rank's time
-    assert abs(out["value"] - 2 * 64 * 2 / (out["ms_per_step"] * 2e-3)) < 1e-6 * out["value"]
+    assert abs(out["value"] - 2 * 256 * 2 / (out["ms_per_step"] * 2e-3)) < 1e-6 * out["value"]
     leg = out["scan_to_map"]
     assert "error" not in leg, leg
     assert leg["all_ranks_hold_the_same_steps"] is True and leg["iterations"] == 10

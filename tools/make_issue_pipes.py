@@ -1,5 +1,5 @@
 """Summary of the SQ / TA / L2 counter passes of the fused kernel as the JSON bench.py quotes (CSV files do not travel to the
-GPU box):  python tools/make_issue_pipes.py pmc_sq.csv pmc_ta.csv pmc_l2.csv out.json"""
+GPU box):  python tools/make_issue_pipes.py pmc_sq.csv pmc_ta.csv pmc_l2.csv out.json [tag [pairs per launch]]"""
 import csv
 import json
 import sys
@@ -24,7 +24,7 @@ def fractions(kernel):
 
 
 tag = sys.argv[5] if len(sys.argv) > 5 else "r02"
-out = {"kernel": "k_ls_batch<1>", "workload": "sequence", "pairs_per_launch": 64}
+out = {"kernel": "k_ls_batch<1>", "workload": "sequence", "pairs_per_launch": int(sys.argv[6]) if len(sys.argv) > 6 else 64}
 out.update(fractions("k_ls_batch<1>"))
 out.update({
        # the all-rings launch of iteration 0 is a kernel of its own since the pooled search

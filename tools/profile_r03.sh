@@ -30,7 +30,8 @@ for t in fetch:f:pmc_FETCH_SIZE write:w:pmc_WRITE_SIZE cf:f:calib_FETCH_SIZE cw:
   python tools/rocpd_export.py pmc $O/$d/${o}_results.db $O/$name.csv
 done
 python tools/make_traffic.py $O/bench_line.json $O/pmc_FETCH_SIZE.csv $O/pmc_WRITE_SIZE.csv $O/calib_FETCH_SIZE.csv $O/calib_WRITE_SIZE.csv $O/traffic.json > /dev/null
-python tools/make_issue_pipes.py $O/pmc_sq.csv $O/pmc_ta.csv $O/pmc_l2.csv $O/issue_pipes.json r03
+P=$(python -c "import json; print(json.loads(open('$O/bench_line.json').read().strip().splitlines()[-1])['config']['pairs_per_gpu_per_step'])")
+python tools/make_issue_pipes.py $O/pmc_sq.csv $O/pmc_ta.csv $O/pmc_l2.csv $O/issue_pipes.json r03 $P
 python tools/kstats.py $O/seq_kernel_stats.csv > $O/kstats.txt; sed -n 1,8p $O/kstats.txt
 cp $O/chain.log $O/chain.txt; cp $O/vox.log $O/voxel_sweep.txt; cp $O/grid.log $O/grid.txt; cp $O/nn.log $O/nn_calls.txt
 rm -rf $O/kt $O/chain $O/vox $O/grid $O/nn $O/fetch $O/write $O/cf $O/cw $O/sq $O/ta $O/l2
