@@ -556,6 +556,33 @@ def odometry_leg(raws, device):
         devs.append(dev_ms)
         voxels = vox.stored_voxels
         vox.cleanup()
+    # the same drive with the map output attached: 2 m voxels, every voxel a frame stages goes into a cell grid on the device
+    from pointcloudprocessing_amd import CellGrid, MapSink
+    sink_walls, sink_points, sink_voxels = [], 0, 0
+    for rep in range(4):
+        chain.reset()
+        grid = CellGrid(np.zeros((0, 3)), cell=1.0, device=device)
+        vox = Voxelizer(cs, None)
+        vox.separate_colors, vox.filter_outliers = False, False
+        vox.init(2.0)
+        vox.voxman = MapSink(grid, compute=cs)      # switches the device point store on: after the reset, before the first frame
+        sink = vox.voxman
+        cs.synchronize()
+        c0 = time.perf_counter()
+        pending = []
+        for lo in range(0, F, 10):
+            hi = min(F, lo + 10)
+            pending.append(chain.submit([pinned[k] for k in range(lo, hi)], rows[lo:hi], point_to_plane=True, iterations=MAX_ITER,
+                                        tol=TOL, voxelizer=vox))
+            if len(pending) == 2:
+                chain.collect(pending.pop(0))
+        for t in pending:
+            chain.collect(t)
+        grid.synchronize()
+        sink_walls.append(time.perf_counter() - c0)
+        sink_points, sink_voxels = sink.points_fed, sink.voxels_fed
+        vox.cleanup()
+        grid.cleanup()
     chain.close()
     pinned.close()
     # the same drive frame by frame on the host
@@ -588,6 +615,10 @@ def odometry_leg(raws, device):
             "frames_per_s": F / wall, "ms_per_frame": wall / F * 1e3, "device_ms_per_frame": float(np.median(devs[1:])) / F,
             "frames_per_s_best": F / min(walls[1:]), "voxels": int(voxels), "path_m": path,
             "iterations_per_frame": float(np.mean([len(t[4]) for t in track[1:]])),
+            "with_map_output": {"what": "the same drive with 2 m voxels and every voxel a frame stages handed to a cell grid on the "
+                                        "device (MapSink through the staged-points log)",
+                                "frames_per_s": F / float(np.median(sink_walls[1:])), "points_in_map": int(sink_points),
+                                "voxels_staged": int(sink_voxels)},
             "host_driven": {"what": "EnvironmentConstructor.calculateTransition_imu per frame (decoded clouds on the host, NumPy "
                                     "placement and pose algebra, device loop, Voxelizer.addPoints from host arrays)",
                             "frames_per_s": F / float(np.median(host[1:])), "ms_per_frame": float(np.median(host[1:])) / F * 1e3},
