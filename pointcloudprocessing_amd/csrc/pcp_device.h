@@ -64,11 +64,13 @@ __device__ __forceinline__ float4 unit_sphere(const float4 p, const float4 o) {
 #ifndef PCP_SCALAR_LEVELS
 #define PCP_SCALAR_LEVELS 1       // search levels at which the whole wave stands at one place read it through the scalar cache
 #endif
+#ifndef PCP_AZ_BINS
 #define PCP_AZ_BINS 64            // azimuth bins of the per-ring elevation table
 // 0.999 * (sin(0.99 * 2 pi / PCP_AZ_BINS) - 1e-5)^2, rounded down: squared sine of the smallest
 // azimuth gap between a query and a target point two or more bins away, with the margins of
 // ring_lower_bound.
 #define PCP_AZ_FAR 0.0094050f
+#endif
 
 // Arrays the search gathers from are addressed as GLOBAL memory explicitly: pointers that reach a
 // kernel through a descriptor in device memory are generic to the compiler, and generic (flat) loads
