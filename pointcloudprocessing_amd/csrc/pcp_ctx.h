@@ -7,6 +7,9 @@
 #include <vector>
 
 #define PCP_BLOCK 64   // threads per block of the search kernels
+#ifndef PCP_LS_THREADS
+#define PCP_LS_THREADS 256         // threads per block of the hinted launches of a batch (k_ls_batch): the block shares its ring searches
+#endif
 
 struct IcpState {
     double R[9];

@@ -559,6 +559,98 @@ __device__ __forceinline__ int find_closest_pooled(const Target& T, const float4
     return glob;
 }
 
+// The hinted search of find_closest for a whole block of PCP_LS_THREADS queries: every query's hinted ring in lock step
+// (all lanes busy), then the other rings of its range that the bounds cannot rule out against that first distance go,
+// offset by offset and thread by thread, onto a list the block shares, and the block works the list off one entry per
+// thread (a wave's entries are neighbouring queries on one ring, mostly).  Results meet in a per-query word as in
+// find_closest_pooled: smallest distance, then lowest ring.  A ring searched although the lock-step walk, with its
+// tightening minimum, would have skipped it can neither hold nor tie the minimum: same (point, ring, distance).
+// Every thread of the block must call (live = false for threads without a hinted query); Z <= 256, n_a <= 2^24.
+struct BlockPool {
+    unsigned long long slot[PCP_LS_THREADS];
+    float4 q[PCP_LS_THREADS], ref[PCP_LS_THREADS];
+    unsigned items[3 * PCP_LS_THREADS];
+    int count[3][PCP_LS_THREADS / 64];
+};
+
+__device__ __forceinline__ int find_closest_block(const Target& T, const float4 q, const bool live, float& hint, BlockPool& P) {
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const float4 v = make_float4(q.x - T.o.x, (q.y - T.o.y) - PCP_LIDAR_OFF_Y, q.z - T.o.z, q.w - T.o.w);
+    const float rho2 = dot4(v, v);
+    const float len = sqrtf(rho2);
+    const float4 ref = make_float4(v.x / len, v.y / len, v.z / len, v.w / len);   // == unit_sphere(q, o)
+    const float sq = ref.y;
+    const float cq = sqrtf(ref.x * ref.x + ref.z * ref.z + ref.w * ref.w);
+    const bool can_prune = cq > 0.05f;
+    const gf4_t my_bins = T.bins + (size_t)az_bin(ref.x, ref.z) * T.Z;
+    const float far = (v.x * v.x + v.z * v.z) * PCP_AZ_FAR;
+    float mind = PCP_BIG;
+    int glob = 0, ring = -1, from = 0, to = 0, centre = 0;
+    if (live) {
+        const int h = (int)hint;
+        from = max(0, h - 2);
+        to = min(T.Z, h + 2);
+        centre = min(max(h, from), to - 1);
+        const int2 se = T.scan[centre];
+        int best;
+        float d;
+        ring_window<10, false>(T, q, ref, se.x, se.y, -1, best, d);
+        if (d < mind) { mind = d; glob = best; ring = centre; }
+    }
+    P.slot[t] = (ring >= 0) ? pool_pack(mind, ring, glob) : ~0ull;
+    P.q[t] = q;
+    P.ref[t] = ref;
+    // the other rings of the range in find_closest's order (centre + 1, centre - 1, centre - 2; centre + 2 lies outside)
+    int r3[3];
+    bool want[3];
+    unsigned long long b3[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        r3[j] = (j == 0) ? centre + 1 : centre - j;
+        want[j] = live && r3[j] >= from && r3[j] < to;
+        if (want[j] && can_prune && mind < PCP_BIG) {
+            if (ring_lower_bound(T.stat[r3[j]], sq, cq, rho2) > mind) want[j] = false;
+            else if (ring_bin_lower_bound(ld4(my_bins, r3[j]), sq, cq, rho2, far) > mind) want[j] = false;
+        }
+        b3[j] = __ballot(want[j]);
+        if (lane == 0) P.count[j][wave] = __popcll(b3[j]);
+    }
+    __syncthreads();
+    int total = 0;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        int before = total;
+#pragma unroll
+        for (int w = 0; w < PCP_LS_THREADS / 64; ++w) {
+            const int c = P.count[j][w];
+            if (w < wave) before += c;
+            total += c;
+        }
+        if (want[j]) P.items[before + __popcll(b3[j] & ((1ull << lane) - 1ull))] = (unsigned)t | ((unsigned)r3[j] << 16);
+    }
+    __syncthreads();
+    for (int base = 0; base < total; base += PCP_LS_THREADS) {
+        if (base + t < total) {
+            const int item = (int)P.items[base + t];
+            const int l = item & 0xffff, r = item >> 16;
+            const float4 oq = P.q[l], oref = P.ref[l];
+            const int2 se = T.scan[r];
+            int best;
+            float d;
+            ring_window<10, false>(T, oq, oref, se.x, se.y, -1, best, d);
+            if (d < PCP_BIG) atomicMin(&P.slot[l], pool_pack(d, r, best));
+        }
+    }
+    __syncthreads();
+    const unsigned long long mine = P.slot[t];
+    if (mine != ~0ull) {
+        ring = (int)((mine >> 24) & 255ull);
+        glob = (int)(mine & 0xFFFFFFull);
+    }
+    if (live && ring >= 0) hint = (float)ring;
+    return glob;
+}
+
 // The all-rings search (hint -1) of find_closest with K lanes per query, K a power of two <= 64 and the
 // K lanes adjacent: lane `sub` takes the offsets k = sub, sub + K, ... of the same outward walk, the K
 // running minima are shared after every round (they only serve the bound tests, and a ring whose lower

@@ -279,7 +279,7 @@ struct LsArgs {
     int skip_store_iter;      // the dispatch (st->iter) whose moved points nobody will read: not written back (-1 = none)
 };
 
-template <int MODE, bool F64SRC, bool POOL = false>
+template <int MODE, bool F64SRC, int POOL = 0>
 __device__ __forceinline__ void ls_body(const LsArgs& A, char* smem, const unsigned block) {
     const float4* __restrict__ a = A.a;
     const float4* __restrict__ normals = A.normals;
@@ -327,7 +327,16 @@ __device__ __forceinline__ void ls_body(const LsArgs& A, char* smem, const unsig
     if (!debug) {
         float h = in ? hint[i] : -1.0f;
         bool pooled = false;
-        if (POOL) {
+        if (POOL == 2) {
+            // hinted launches: the block shares the ring searches behind every query's hinted ring
+            __shared__ BlockPool block_pool;
+            if (T.Z <= 256) {              // uniform: every thread of the block takes part
+                const bool hinted = in && h != -1.0f;
+                const int found = find_closest_block(T, q, hinted, h, block_pool);
+                if (hinted) { nn = found; pooled = true; }
+            }
+        }
+        if (POOL == 1) {
             // the wave's ring searches behind the first one run as dense passes
             __shared__ unsigned long long pool_slot[64];
             __shared__ unsigned short pool_items[128];
@@ -523,14 +532,18 @@ k_first_rings_ind(const LsArgs* __restrict__ desc) {
 #ifndef PCP_LS_WAVES
 #define PCP_LS_WAVES 8      // resident waves per SIMD the register budget is set for
 #endif
+#ifndef PCP_LS_BLOCK_POOL
+#define PCP_LS_BLOCK_POOL 1 // hinted launches: the ring searches behind the hinted ring as a list the block shares (find_closest_block);
+                            // 0 with -DPCP_LS_THREADS=64 restores one wave per block walking its rings in lock step
+#endif
 template <int MODE>
-__global__ void __launch_bounds__(PCP_BLOCK) __attribute__((amdgpu_waves_per_eu(PCP_LS_WAVES, PCP_LS_WAVES))) k_ls_batch(const LsArgs* __restrict__ all) {
+__global__ void __launch_bounds__(PCP_LS_THREADS) __attribute__((amdgpu_waves_per_eu(PCP_LS_WAVES, PCP_LS_WAVES))) k_ls_batch(const LsArgs* __restrict__ all) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     unsigned pair, block;
     pair_and_block(pair, block);
     const LsArgs A = all[pair];
-    if ((int)(block * PCP_BLOCK) >= A.n_b) return;
-    ls_body<MODE, true>(A, smem, block);
+    if ((int)(block * PCP_LS_THREADS) >= A.n_b) return;
+    ls_body<MODE, true, PCP_LS_BLOCK_POOL ? 2 : 0>(A, smem, block);
 }
 
 // The first dispatch of freshly prepared pairs (no query has a hint yet): the same kernel with the all-rings search
@@ -545,7 +558,7 @@ __global__ void __launch_bounds__(PCP_BLOCK) __attribute__((amdgpu_waves_per_eu(
     pair_and_block(pair, block);
     const LsArgs A = all[pair];
     if ((int)(block * PCP_BLOCK) >= A.n_b) return;
-    ls_body<MODE, true, true>(A, smem, block);
+    ls_body<MODE, true, 1>(A, smem, block);
 }
 
 
@@ -1562,8 +1575,8 @@ int pcp_batch_icp_launch(pcp_batch* b, int mode, int max_iter, float tol, int fu
         if ((it == 0 && use_pool() >= 1) || use_pool() >= 2) {
             if (mode == PCP_MODE_POINT) hipLaunchKernelGGL((k_ls_batch_first<PCP_MODE_POINT>), grid, block, sm, b->stream, b->ls_dev);
             else hipLaunchKernelGGL((k_ls_batch_first<PCP_MODE_PLANE>), grid, block, sm, b->stream, b->ls_dev);
-        } else if (mode == PCP_MODE_POINT) hipLaunchKernelGGL((k_ls_batch<PCP_MODE_POINT>), grid, block, sm, b->stream, b->ls_dev);
-        else hipLaunchKernelGGL((k_ls_batch<PCP_MODE_PLANE>), grid, block, sm, b->stream, b->ls_dev);
+        } else if (mode == PCP_MODE_POINT) hipLaunchKernelGGL((k_ls_batch<PCP_MODE_POINT>), dim3(cdiv(max_nb, PCP_LS_THREADS), n), dim3(PCP_LS_THREADS), sm, b->stream, b->ls_dev);
+        else hipLaunchKernelGGL((k_ls_batch<PCP_MODE_PLANE>), dim3(cdiv(max_nb, PCP_LS_THREADS), n), dim3(PCP_LS_THREADS), sm, b->stream, b->ls_dev);
         PCP_CHECK(hipGetLastError());
         if (b->profile) {
             PCP_CHECK(hipEventRecord(b->prof_events[2 * it + 1], b->stream));

@@ -516,8 +516,8 @@ int pcp_seq_submit_placed(pcp_seq* s, const float* const* raw_xyzi, const int* n
         if ((it == 0 && use_pool() >= 1) || use_pool() >= 2) {
             if (mode == PCP_MODE_POINT) hipLaunchKernelGGL((k_ls_batch_first<PCP_MODE_POINT>), grid, block, sm, q, s->ls_dev);
             else hipLaunchKernelGGL((k_ls_batch_first<PCP_MODE_PLANE>), grid, block, sm, q, s->ls_dev);
-        } else if (mode == PCP_MODE_POINT) hipLaunchKernelGGL((k_ls_batch<PCP_MODE_POINT>), grid, block, sm, q, s->ls_dev);
-        else hipLaunchKernelGGL((k_ls_batch<PCP_MODE_PLANE>), grid, block, sm, q, s->ls_dev);
+        } else if (mode == PCP_MODE_POINT) hipLaunchKernelGGL((k_ls_batch<PCP_MODE_POINT>), dim3(cdiv(s->max_points, PCP_LS_THREADS), P), dim3(PCP_LS_THREADS), sm, q, s->ls_dev);
+        else hipLaunchKernelGGL((k_ls_batch<PCP_MODE_PLANE>), dim3(cdiv(s->max_points, PCP_LS_THREADS), P), dim3(PCP_LS_THREADS), sm, q, s->ls_dev);
         if (s->profile) {
             PCP_CHECK(hipEventRecord(s->prof_events[2 * it + 1], q));
             s->prof_launches = it + 1;
