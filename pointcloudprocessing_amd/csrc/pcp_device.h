@@ -98,7 +98,8 @@ struct Target {
     gf4_t ua;                        // unit_sphere(a[i])
     const int2* scan;                // (begin, end_inclusive) per ring, in LDS
     const float4* stat;              // per ring (sin, cos) of its lowest and highest elevation, in LDS
-    gf4_t bins;                      // [azimuth bin][ring]: the same for the ring's points in bins b-1, b, b+1
+    gf4_t bins;                      // [azimuth bin][ring]: the same for the ring's points in bins b-1, b, b+1; behind these
+                                     // PCP_AZ_BINS x Z entries as many with the range band (lowest, highest) of the same points
     int n_a;
     int Z;                           // lens_data.z
     int Zs;                          // rings [Zs, Z) are copies of ring Zs - 1 (the padding rows of the table)
@@ -358,6 +359,25 @@ __device__ __forceinline__ float ring_bin_lower_bound(const float4 st, const flo
     return fminf(near, far);
 }
 
+// The bound a search tests a ring with before it visits it: the ring's points in the query's azimuth neighbourhood (bins
+// b-1 .. b+1) are bounded by their elevation band and by their range band -- | |q'| - |a'| | <= |q' - a'|, both lengths from
+// the same expressions (ring_stats_body) -- all others are at least `far` away.  The range band is only fetched when the
+// elevation band alone does not rule the ring out.  2e-5 of the two ranges and 1e-5 m are far above the float32 rounding
+// of the three square roots involved.  Used where a ring visit saved is worth the second look-up: the block-shared hinted
+// search (2.50 -> 2.35 ms per 256 pairs); in the all-rings first dispatch, whose time is its bound tests, it cost more than
+// it saved (5.5 -> 6.2 ms), and a single pair in flight did not notice it.
+__device__ __forceinline__ float ring_bound(const Target& T, const gf4_t my_bins, const int r, const float sq, const float cq,
+                                            const float rho2, const float len, const float far, const float mind) {
+    const float4 st = ld4(my_bins, r);
+    float near = (st.y < 0.0f) ? PCP_BIG : ring_lower_bound(st, sq, cq, rho2);
+    if (near <= mind && far > mind) {
+        const float4 rb = ld4(my_bins + (size_t)PCP_AZ_BINS * T.Z, r);
+        const float gap = fmaxf(len - rb.y, rb.x - len) - ((len + rb.y) * 2e-5f + 1e-5f);
+        if (gap > 0.0f && rb.y < PCP_BIG) near = fmaxf(near, (gap * gap) * 0.999f);
+    }
+    return fminf(near, far);
+}
+
 // The ring an all-rings search starts at: one whose band is near the query's elevation.  Which ring that is only
 // decides the order of the visits, never the result, so it need not be THE nearest band: neighbouring scan rings are
 // neighbours in elevation, so every fourth ring's bound is looked at and then the rings around the best of those
@@ -610,7 +630,7 @@ __device__ __forceinline__ int find_closest_block(const Target& T, const float4 
         want[j] = live && r3[j] >= from && r3[j] < to;
         if (want[j] && can_prune && mind < PCP_BIG) {
             if (ring_lower_bound(T.stat[r3[j]], sq, cq, rho2) > mind) want[j] = false;
-            else if (ring_bin_lower_bound(ld4(my_bins, r3[j]), sq, cq, rho2, far) > mind) want[j] = false;
+            else if (ring_bound(T, my_bins, r3[j], sq, cq, rho2, len, far, mind) > mind) want[j] = false;
         }
         b3[j] = __ballot(want[j]);
         if (lane == 0) P.count[j][wave] = __popcll(b3[j]);

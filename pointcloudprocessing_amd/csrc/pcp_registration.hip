@@ -72,13 +72,16 @@ __device__ __forceinline__ float key_float(const int k) { return __int_as_float(
 // unit-vector elevation among its points, for the whole ring (stat[r]) and, per
 // azimuth bin b, for the points in bins b-1, b, b+1 (bins[b][r]; cos < 0 = none).
 // One wave per ring.
-__device__ __forceinline__ void ring_stats_body(const float4* __restrict__ ua, const int2* __restrict__ scan,
-                                                int Z, float4* __restrict__ stat, float4* __restrict__ bins,
-                                                const int r) {
-    __shared__ int blo[PCP_AZ_BINS], bhi[PCP_AZ_BINS];
+__device__ __forceinline__ void ring_stats_body(const float4* __restrict__ a, const float4 o, const float4* __restrict__ ua,
+                                                const int2* __restrict__ scan, int Z, float4* __restrict__ stat,
+                                                float4* __restrict__ bins, const int r) {
+    __shared__ int blo[PCP_AZ_BINS], bhi[PCP_AZ_BINS], rlo[PCP_AZ_BINS], rhi[PCP_AZ_BINS];
     if (r >= Z) return;
     const int2 se = scan[r];
-    for (int b = threadIdx.x; b < PCP_AZ_BINS; b += 64) { blo[b] = float_key(2.0f); bhi[b] = float_key(-2.0f); }
+    for (int b = threadIdx.x; b < PCP_AZ_BINS; b += 64) {
+        blo[b] = float_key(2.0f); bhi[b] = float_key(-2.0f);
+        rlo[b] = float_key(PCP_BIG); rhi[b] = float_key(0.0f);
+    }
     __syncthreads();
     float lo = 2.0f, hi = -2.0f;
     bool bad = false;
@@ -90,6 +93,16 @@ __device__ __forceinline__ void ring_stats_body(const float4* __restrict__ ua, c
         const int b = az_bin(u.x, u.z);
         atomicMin(&blo[b], float_key(u.y));
         atomicMax(&bhi[b], float_key(u.y));
+        // the point's range from the sensor, by the expressions a query's range is computed with (find_closest)
+        const float4 pa = a[p];
+        const float4 v = make_float4(pa.x - o.x, (pa.y - o.y) - PCP_LIDAR_OFF_Y, pa.z - o.z, pa.w - o.w);
+        const float rho = sqrtf(dot4(v, v));
+        if (rho == rho) {
+            atomicMin(&rlo[b], float_key(rho));
+            atomicMax(&rhi[b], float_key(rho));
+        } else {
+            bad = true;
+        }
     }
 #pragma unroll
     for (int s = 32; s > 0; s >>= 1) {
@@ -113,13 +126,18 @@ __device__ __forceinline__ void ring_stats_body(const float4* __restrict__ ua, c
         else out = make_float4(mlo, (float)sqrt(fmax(0.0, 1.0 - (double)mlo * (double)mlo)),
                                mhi, (float)sqrt(fmax(0.0, 1.0 - (double)mhi * (double)mhi)));
         bins[(size_t)b * Z + r] = out;
+        // second half of the table: the range band of the same points (lowest, highest); (0, BIG) rules nothing out
+        const float qlo = key_float(min(rlo[b], min(rlo[l], rlo[h])));
+        const float qhi = key_float(max(rhi[b], max(rhi[l], rhi[h])));
+        const bool none = unusable || mlo > mhi || !(qlo <= qhi);
+        bins[(size_t)(PCP_AZ_BINS + b) * Z + r] = none ? make_float4(0.0f, PCP_BIG, 0.0f, 0.0f) : make_float4(qlo, qhi, 0.0f, 0.0f);
     }
 }
 
 __global__ void __launch_bounds__(64)
-k_ring_stats(const float4* __restrict__ ua, const int2* __restrict__ scan, int Z, float4* __restrict__ stat,
-             float4* __restrict__ bins) {
-    ring_stats_body(ua, scan, Z, stat, bins, blockIdx.x);
+k_ring_stats(const float4* __restrict__ a, const float4 o, const float4* __restrict__ ua, const int2* __restrict__ scan, int Z,
+             float4* __restrict__ stat, float4* __restrict__ bins) {
+    ring_stats_body(a, o, ua, scan, Z, stat, bins, blockIdx.x);
 }
 
 // Prepare-phase kernels for a batch: blockIdx.y / blockIdx.z selects the pair.
@@ -137,7 +155,7 @@ __global__ void k_unit_batch(const PrepArgs* __restrict__ all) {
 
 __global__ void __launch_bounds__(64) k_ring_stats_batch(const PrepArgs* __restrict__ all) {
     const PrepArgs P = all[blockIdx.y];
-    ring_stats_body(P.ua, P.scan, P.Z, P.stat, P.bins, blockIdx.x);
+    ring_stats_body(P.a, P.o, P.ua, P.scan, P.Z, P.stat, P.bins, blockIdx.x);
 }
 
 // NearestNeighbourScan.glsl:1-35.  One wave per block = one shader workgroup.
@@ -934,7 +952,7 @@ int pcp_create(int device, int max_points, int max_scans, pcp_ctx** out) {
     A((void**)&c->nn_idx, 2 * n * sizeof(uint32_t));      // indices, and behind them the squared distances (one copy fetches both)
     A((void**)&c->scan, (size_t)max_scans * sizeof(int2));
     A((void**)&c->ring_stat, (size_t)max_scans * sizeof(float4));
-    A((void**)&c->ring_bins, (size_t)max_scans * PCP_AZ_BINS * sizeof(float4));
+    A((void**)&c->ring_bins, (size_t)max_scans * PCP_AZ_BINS * 2 * sizeof(float4));      // elevation bands, then range bands
     A((void**)&c->partials, (size_t)n1 * PCP_PSTRIDE * sizeof(float));
     A((void**)&c->lvl0, (size_t)n2 * PCP_PSTRIDE * sizeof(float));
     A((void**)&c->lvl1, (size_t)n2 * PCP_PSTRIDE * sizeof(float));
@@ -1012,7 +1030,7 @@ int pcp_prepare_resident(pcp_ctx* c, int with_normals) {
     if (!c->have_target) return pcp_fail("no target: call pcp_set_target first");
     hipLaunchKernelGGL(k_unit, dim3(cdiv(c->n_a, 256)), dim3(256), 0, c->stream, c->a, c->ua, c->n_a, c->origin);
     PCP_CHECK(hipGetLastError());
-    hipLaunchKernelGGL(k_ring_stats, dim3(c->n_scans), dim3(64), 0, c->stream, c->ua, c->scan, c->n_scans, c->ring_stat, c->ring_bins);
+    hipLaunchKernelGGL(k_ring_stats, dim3(c->n_scans), dim3(64), 0, c->stream, c->a, c->origin, c->ua, c->scan, c->n_scans, c->ring_stat, c->ring_bins);
     PCP_CHECK(hipGetLastError());
     if (int e = pcp_reset_hints(c)) return e;
     if (with_normals) {

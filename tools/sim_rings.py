@@ -140,3 +140,37 @@ def bands(nb, width, use_range):
     return np.minimum(near, ((rxz * np.sin(ang)) ** 2)[:, None])
 for nb, width, rng in ((64, 1, False), (64, 1, True), (256, 1, False), (256, 1, True), (1024, 1, True), (1024, 2, True), (2048, 2, True)):
     hinted(np.maximum(whole, bands(nb, width, rng)), f"bins {nb} width {width} range {rng}")
+print("---- the block-shared search: hinted ring first, the other rings of the range listed against that first distance only")
+def listed(lbm, name, block=256):
+    d0 = D[np.arange(Q), h]
+    items = np.zeros(Q)
+    for off in (1, -1, -2):
+        r = h + off
+        ok = (r >= np.maximum(0, h - 2)) & (r < np.minimum(Z, h + 2))
+        rr = np.clip(r, 0, Z - 1)
+        items += ok & (lbm[np.arange(Q), rr] <= d0)
+    nblk = Q // block
+    per_block = items[:nblk * block].reshape(nblk, block).sum(axis=1)
+    waves_per_block = block // 64
+    passes = waves_per_block + np.ceil(per_block / 64)
+    print(f"{name:34s}: listed rings/query {items.mean():.2f}, wave passes per {block} queries {passes.mean():.2f} (lock step as built: see above x {waves_per_block})")
+def simple_range(nb):
+    """per (ring, bin +-1) the range band; bound = (distance of the query's range from the band)^2"""
+    ba = np.clip((az_a * nb / (2 * np.pi)).astype(int), 0, nb - 1)
+    bq = np.clip((az_q * nb / (2 * np.pi)).astype(int), 0, nb - 1)
+    r_lo = np.full((Z, nb), np.inf); r_hi = np.full((Z, nb), -np.inf)
+    for r, (s, e) in enumerate(lines):
+        sl = slice(s, e + 1)
+        lo1 = np.full(nb, np.inf); hi1 = np.full(nb, -np.inf)
+        np.minimum.at(lo1, ba[sl], rho_a[sl]); np.maximum.at(hi1, ba[sl], rho_a[sl])
+        r_lo[r] = np.min([np.roll(lo1, k) for k in (-1, 0, 1)], axis=0)
+        r_hi[r] = np.max([np.roll(hi1, k) for k in (-1, 0, 1)], axis=0)
+    g = gap(rho_q[:, None], r_lo[:, bq].T, r_hi[:, bq].T)
+    return np.where(np.isfinite(g), g, 0.0) ** 2
+listed(lb, "as built")
+rb = simple_range(64)
+near_both = np.maximum(near_elev, np.where(none, np.inf, rb))
+listed(np.maximum(whole, np.minimum(near_both, far[:, None])), "plus range band (simple gap)")
+listed(np.maximum(whole, bands(64, 1, True)), "plus range band (joint bound)")
+listed(D, "perfect knowledge")
+hinted(np.maximum(whole, np.minimum(near_both, far[:, None])), "lock step, simple range band")
