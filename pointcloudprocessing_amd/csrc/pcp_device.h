@@ -65,11 +65,14 @@ __device__ __forceinline__ float4 unit_sphere(const float4 p, const float4 o) {
 #define PCP_SCALAR_LEVELS 1       // search levels at which the whole wave stands at one place read it through the scalar cache
 #endif
 #ifndef PCP_AZ_BINS
-#define PCP_AZ_BINS 64            // azimuth bins of the per-ring elevation table
+#define PCP_AZ_BINS 128           // azimuth bins of the per-ring elevation and range tables.  With the range bands finer bins
+                                  // pay in the batched hinted launches (64 / 128 / 256 bins: 2.34 / 2.24 / 2.21 ms per launch of
+                                  // 256 pairs) and cost a single pair in flight, whose pre-pass waits for the larger table
+                                  // (the driver chain: 0.462 / 0.475 ms per frame at 64 / 256 bins)
 // 0.999 * (sin(0.99 * 2 pi / PCP_AZ_BINS) - 1e-5)^2, rounded down: squared sine of the smallest
 // azimuth gap between a query and a target point two or more bins away, with the margins of
-// ring_lower_bound.
-#define PCP_AZ_FAR 0.0094050f
+// ring_lower_bound (64 bins: 0.0094050f, 256: 0.00058921f).
+#define PCP_AZ_FAR 0.0023564f
 #endif
 
 // Arrays the search gathers from are addressed as GLOBAL memory explicitly: pointers that reach a
