@@ -174,3 +174,8 @@ listed(np.maximum(whole, np.minimum(near_both, far[:, None])), "plus range band 
 listed(np.maximum(whole, bands(64, 1, True)), "plus range band (joint bound)")
 listed(D, "perfect knowledge")
 hinted(np.maximum(whole, np.minimum(near_both, far[:, None])), "lock step, simple range band")
+print("---- the all-rings walk with the range bands in its bounds")
+lb_saved = lb
+lb = np.maximum(whole, np.minimum(near_both, far[:, None]))
+walk(8)
+lb = lb_saved
