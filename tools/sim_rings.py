@@ -179,3 +179,15 @@ lb_saved = lb
 lb = np.maximum(whole, np.minimum(near_both, far[:, None]))
 walk(8)
 lb = lb_saved
+print("---- the all-rings search as a block-shared list: start ring first, every other ring listed against that first distance")
+def listed_all(lbm, name, block=256):
+    d0 = D[np.arange(Q), centre]
+    cand = lbm <= d0[:, None]
+    cand[np.arange(Q), centre] = False
+    items = cand.sum(axis=1)
+    nblk = Q // block
+    per_block = items[:nblk * block].reshape(nblk, block).sum(axis=1)
+    passes = block // 64 + np.ceil(per_block / 64)
+    print(f"{name:34s}: listed rings/query {items.mean():.2f}, wave passes per wave {passes.mean() / (block // 64):.2f}")
+listed_all(lb_saved, "as built (elevation bands)")
+listed_all(np.maximum(whole, np.minimum(near_both, far[:, None])), "plus range bands")
