@@ -483,6 +483,20 @@ def test_two_thousand_rings_match_oracle_bitwise():
         H, bb = cs.dispatchPointPlane(b)
         rH, rb = spl.dispatch_plane(b)
         assert np.array_equal(bits(H), bits(rH)) and np.array_equal(bits(bb), bits(rb))
+        # more rings than the batched launches' shared list can name: they fall back to the lock-step walk
+        from pointcloudprocessing_amd import IcpBatch
+        dx, cv, hb, moved = cs.icpRun(b, MODE_PLANE, 3, full_iter=True, want_hb=True, want_points=True)
+        assert np.array_equal(bits(hb[0][:6, :6]), bits(rH)) and np.array_equal(bits(hb[0][:6, 6]), bits(rb))
+        batch = IcpBatch([cs])
+        try:
+            batch.upload_sources([b])
+            batch.prepare(True)
+            batch.launch(MODE_PLANE, 3, full_iter=True)
+            (dx2, cv2, hb2, moved2), = batch.results(3, want_hb=True, want_points=True)
+        finally:
+            batch.close()
+        assert np.array_equal(bits(dx), bits(dx2)) and np.array_equal(bits(hb), bits(hb2))
+        assert np.array_equal(moved.view(np.uint64), moved2.view(np.uint64))
     finally:
         cs.cleanup()
 
@@ -549,6 +563,18 @@ def test_device_loop_with_non_finite_source_points_matches_oracle(compute):
         assert np.array_equal(bits(hb[i][:6, 6]), bits(bb)), f"b at iteration {i}"
         assert np.array_equal(bits(dx[i]), bits(d)), f"dx at iteration {i}"
     assert np.isnan(moved[10]).all() and np.isfinite(moved[11]).all()
+    # the batched launches (blocks of queries sharing their ring searches) on the same pair: the same steps, tiles and points
+    from pointcloudprocessing_amd import IcpBatch
+    batch = IcpBatch([compute])
+    try:
+        batch.upload_sources([b])
+        batch.prepare(True)
+        batch.launch(MODE_PLANE, 6)
+        (dx2, cv2, hb2, moved2), = batch.results(6, want_hb=True, want_points=True)
+    finally:
+        batch.close()
+    assert len(dx2) == len(dx) and np.array_equal(bits(dx2), bits(dx)) and np.array_equal(bits(hb2[:len(dx)]), bits(hb[:len(dx)]))
+    assert np.array_equal(moved.view(np.uint64), moved2.view(np.uint64))
 
 
 def test_transposed_source_arrays_take_the_row_upload_and_change_nothing(compute):
