@@ -191,54 +191,10 @@ def listed_all(lbm, name, block=256):
     print(f"{name:34s}: listed rings/query {items.mean():.2f}, wave passes per wave {passes.mean() / (block // 64):.2f}")
 listed_all(lb_saved, "as built (elevation bands)")
 listed_all(np.maximum(whole, np.minimum(near_both, far[:, None])), "plus range bands")
-print("---- the all-rings walk confined by cumulative bands: how many rings remain between the two cut-offs after the first pass")
-pmax_hi = np.maximum.accumulate(ring_hi)                       # highest elevation among rings 0 .. r
-smin_lo = np.minimum.accumulate(ring_lo[::-1])[::-1]           # lowest elevation among rings r .. Z-1
 d0 = D[np.arange(Q), centre]
 def bound_gap(g, rho):
     return (rho * np.sin(np.minimum(np.maximum(g, 0.0), np.pi / 2))) ** 2
-width = np.zeros(Q, dtype=int)
-for qq in range(Q):
-    below = bound_gap(elev_q[qq] - pmax_hi, rho_q[qq]) > d0[qq]           # all rings <= r ruled out
-    above = bound_gap(smin_lo - elev_q[qq], rho_q[qq]) > d0[qq]           # all rings >= r ruled out
-    lo_cut = np.nonzero(below)[0].max() + 1 if below.any() else 0
-    hi_cut = np.nonzero(above)[0].min() if above.any() else Z
-    width[qq] = max(1, hi_cut - lo_cut)
-per_wave = width.reshape(W, 64).max(axis=1)
-print("rings left per query: mean %.1f, median %d, 90th %d; per wave (the widest lane sets the loop): mean %.1f of %d" %
-      (width.mean(), np.median(width), np.percentile(width, 90), per_wave.mean(), Z))
-bhi = np.where(np.isfinite(be_hi), be_hi, -np.inf); blo_ = np.where(np.isfinite(be_lo), be_lo, np.inf)
-pmax_b = np.maximum.accumulate(bhi, axis=0)                     # (Z, NB): highest elevation in the bin neighbourhood among rings 0 .. r
-smin_b = np.minimum.accumulate(blo_[::-1], axis=0)[::-1]
-width = np.zeros(Q, dtype=int)
-for qq in range(Q):
-    b = bin_q[qq]
-    lim = min(d0[qq], far[qq])                                   # points of other bins are only known to be `far` away
-    below = bound_gap(elev_q[qq] - pmax_b[:, b], rho_q[qq]) > lim
-    above = bound_gap(smin_b[:, b] - elev_q[qq], rho_q[qq]) > lim
-    if far[qq] <= d0[qq]:
-        below[:] = False; above[:] = False
-    lo_cut = np.nonzero(below)[0].max() + 1 if below.any() else 0
-    hi_cut = np.nonzero(above)[0].min() if above.any() else Z
-    width[qq] = max(1, hi_cut - lo_cut)
-per_wave = width.reshape(W, 64).max(axis=1)
-print("per-bin cumulative bands: rings left per query: mean %.1f, median %d, 90th %d; per wave: mean %.1f of %d" %
-      (width.mean(), np.median(width), np.percentile(width, 90), per_wave.mean(), Z))
-for skip_first, skip_last in ((0, 1), (1, 1), (0, 2), (2, 2)):
-    Zi = Z - skip_last
-    pm = np.maximum.accumulate(ring_hi[skip_first:Zi]); sm_ = np.minimum.accumulate(ring_lo[skip_first:Zi][::-1])[::-1]
-    width = np.zeros(Q, dtype=int)
-    for qq in range(Q):
-        below = bound_gap(elev_q[qq] - pm, rho_q[qq]) > d0[qq]
-        above = bound_gap(sm_ - elev_q[qq], rho_q[qq]) > d0[qq]
-        lo_cut = np.nonzero(below)[0].max() + 1 if below.any() else 0
-        hi_cut = np.nonzero(above)[0].min() if above.any() else len(pm)
-        width[qq] = max(1, hi_cut - lo_cut) + skip_first + skip_last
-    per_wave = width.reshape(W, 64).max(axis=1)
-    print("whole-ring cumulative bands without the first %d and last %d rings (those tested one by one): rings left per query mean %.1f, median %d, 90th %d; per wave mean %.1f" %
-          (skip_first, skip_last, width.mean(), np.median(width), np.percentile(width, 90), per_wave.mean()))
-print("ring bands (deg):", np.round(np.degrees(ring_lo[:4]), 1), np.round(np.degrees(ring_hi[:4]), 1), "...", np.round(np.degrees(ring_lo[-3:]), 1), np.round(np.degrees(ring_hi[-3:]), 1))
-print("---- (ring 0 is the highest ring) cumulative bands the right way round")
+print("---- the all-rings walk confined by cumulative bands (ring 0 is the highest ring): rings left between the two cut-offs")
 pmin_lo = np.minimum.accumulate(ring_lo)                        # lowest elevation among rings 0 .. r
 smax_hi = np.maximum.accumulate(ring_hi[::-1])[::-1]            # highest elevation among rings r .. Z-1
 for name, use_d in (("after the first pass (its distance)", d0), ("with the final distance", D.min(axis=1))):
