@@ -43,7 +43,7 @@ struct pcp_ctx {
     float* stage_hint = nullptr;
     struct pcp_batch* batch = nullptr;  // the batch that has adopted this context, if any
     float4* ring_stat = nullptr;   // per ring: (sin, cos) of lowest and highest elevation
-    float4* ring_bins = nullptr;   // the same per ring and azimuth bin (PCP_AZ_BINS per ring)
+    float4* ring_bins = nullptr;   // the same per ring and azimuth bin (PCP_AZ_BINS per ring), then the range bands of the same points
     float *partials = nullptr, *lvl0 = nullptr, *lvl1 = nullptr;
     float *hb_trace = nullptr, *dx_trace = nullptr;   // max_iter_cap x 64 / x 6
     IcpState* state = nullptr;
