@@ -208,3 +208,49 @@ for name, use_d in (("after the first pass (its distance)", d0), ("with the fina
     per_wave = width.reshape(W, 64).max(axis=1)
     print("%s: rings left per query mean %.1f, median %d, 90th %d, 99th %d; per wave (widest lane) mean %.1f" %
           (name, width.mean(), np.median(width), np.percentile(width, 90), np.percentile(width, 99), per_wave.mean()))
+print("---- listed rings with each of the three bins bounded on its own (the neighbours also by the azimuth gap to their edge)")
+def own_bands(nb):
+    ba = np.clip((az_a * nb / (2 * np.pi)).astype(int), 0, nb - 1)
+    e_lo = np.full((Z, nb), np.inf); e_hi = np.full((Z, nb), -np.inf); r_lo = np.full((Z, nb), np.inf); r_hi = np.full((Z, nb), -np.inf)
+    for r, (s_, e_) in enumerate(lines):
+        sl = slice(s_, e_ + 1)
+        np.minimum.at(e_lo[r], ba[sl], elev_a[sl]); np.maximum.at(e_hi[r], ba[sl], elev_a[sl])
+        np.minimum.at(r_lo[r], ba[sl], rho_a[sl]); np.maximum.at(r_hi[r], ba[sl], rho_a[sl])
+    return e_lo, e_hi, r_lo, r_hi
+def three_bins(nb, union):
+    e_lo, e_hi, r_lo, r_hi = own_bands(nb)
+    w = 2 * np.pi / nb
+    bq = np.clip((az_q * nb / (2 * np.pi)).astype(int), 0, nb - 1)
+    off = az_q - bq * w                                              # position inside the bin, 0 .. w
+    out = np.full((Q, Z), np.inf)
+    def one(bins_idx, lateral):
+        el = e_lo[:, bins_idx].T; eh = e_hi[:, bins_idx].T; rl = r_lo[:, bins_idx].T; rh = r_hi[:, bins_idx].T
+        none_ = ~np.isfinite(el)
+        de = np.minimum(gap(elev_q[:, None], el, eh), np.pi / 2)
+        be = (rho_q[:, None] * np.sin(de)) ** 2
+        g = gap(rho_q[:, None], rl, rh)
+        br = np.where(np.isfinite(g), g, 0.0) ** 2
+        b_ = np.maximum(np.maximum(be, br), lateral[:, None])
+        return np.where(none_, np.inf, b_)
+    zero = np.zeros(Q)
+    if union:                                                        # as built: one band over the three bins
+        return None
+    lat_lo = (rxz * np.sin(np.minimum(0.99 * off, np.pi / 2))) ** 2          # points of bin b-1 lie beyond the lower edge
+    lat_hi = (rxz * np.sin(np.minimum(0.99 * (w - off), np.pi / 2))) ** 2
+    b0 = one(bq, zero); bm = one((bq - 1) % nb, lat_lo); bp = one((bq + 1) % nb, lat_hi)
+    far_ = (rxz * np.sin(min(0.99 * w, np.pi / 2))) ** 2
+    return np.maximum(whole, np.minimum(np.minimum(b0, np.minimum(bm, bp)), far_[:, None]))
+def union_bands(nb):
+    e_lo, e_hi, r_lo, r_hi = own_bands(nb)
+    bq = np.clip((az_q * nb / (2 * np.pi)).astype(int), 0, nb - 1)
+    roll3 = lambda x, f: f(f(x, np.roll(x, 1, axis=1)), np.roll(x, -1, axis=1))
+    el = roll3(e_lo, np.minimum)[:, bq].T; eh = roll3(e_hi, np.maximum)[:, bq].T
+    rl = roll3(r_lo, np.minimum)[:, bq].T; rh = roll3(r_hi, np.maximum)[:, bq].T
+    none_ = ~np.isfinite(el)
+    be = (rho_q[:, None] * np.sin(np.minimum(gap(elev_q[:, None], el, eh), np.pi / 2))) ** 2
+    g = gap(rho_q[:, None], rl, rh); br = np.where(np.isfinite(g), g, 0.0) ** 2
+    far_ = (rxz * np.sin(min(0.99 * 2 * np.pi / nb, np.pi / 2))) ** 2
+    return np.maximum(whole, np.minimum(np.where(none_, np.inf, np.maximum(be, br)), far_[:, None]))
+for nb in (128, 256):
+    listed(union_bands(nb), f"{nb} bins, one band over three bins")
+    listed(three_bins(nb, False), f"{nb} bins, three bins on their own")
